@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE model (imported from /root/reference) on the
+synthetic weights/frames of unet-_amd/synthetic.py.  Run in the build container only:
+
+    python oracle/make_golden.py
+
+/root/reference does not exist on the GPU box; only the resulting small fixtures travel.  The
+reference module does `from torchvision import models` at import time (src/models/unetpp.py:9) and
+torchvision is not installed; `models` is only dereferenced under `pretrained_encoder=True`
+(unetpp.py:52-65, never taken by the north-star callers), so empty stub modules are registered first.
+The frame-loop tail (softmax -> np.argmax -> uint8 -> class masks) is evaluated with the same torch /
+numpy calls as infer_two_stage_burr.py:299-304 (that script itself imports cv2, which is absent).
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _load_synthetic():
+    spec = importlib.util.spec_from_file_location("synthetic", os.path.join(ROOT, "unet-_amd", "synthetic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _import_reference():
+    for name in ("torchvision", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.path.insert(0, REF)
+    from src.models.unetpp import NestedUNet  # noqa
+    return NestedUNet
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_reference(NestedUNet, syn, C, ds, wseed, frames_u8, want_intermediates):
+    sd_np = syn.make_state_dict(C, 3, ds, wseed)
+    model = NestedUNet(num_classes=C, input_channels=3, deep_supervision=ds, pretrained_encoder=False)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    model.eval()
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames_u8))
+    inter = {}
+    hooks = []
+    if want_intermediates:
+        names = {"conv0_0": "x0_0", "conv1_0": "x1_0", "conv2_0": "x2_0", "conv3_0": "x3_0", "conv4_0": "x4_0",
+                 "conv3_1": "x3_1", "conv2_2": "x2_2", "conv1_3": "x1_3", "conv0_4": "x0_4"}
+        for mod_name, t_name in names.items():
+            hooks.append(getattr(model, mod_name).register_forward_hook(
+                lambda m, i, o, t=t_name: inter.__setitem__(t, o.detach().clone().numpy())))
+    with torch.no_grad():
+        outputs = model(x)                                   # infer_two_stage_burr.py:294-297
+        if isinstance(outputs, list):
+            outputs = outputs[-1]
+    probs = torch.softmax(outputs, dim=1).cpu().numpy()      # :299 (all frames, not just [0])
+    pred = np.argmax(probs, axis=1).astype(np.uint8)         # :300
+    for h in hooks:
+        h.remove()
+    return sd_np, outputs.numpy(), pred, inter
+
+
+def margin_of(logits):
+    s = np.sort(logits, axis=1)
+    return s[:, -1] - s[:, -2]
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(OUT, exist_ok=True)
+    syn = _load_synthetic()
+    NestedUNet = _import_reference()
+    meta_lines = []
+
+    # ---- small cases: full logits (+ every intermediate for the smallest one)
+    small = [
+        # tag, C, ds, wseed, B, H, W, kind, fseed, intermediates
+        ("s_c3_32x32", 3, True, 2, 1, 32, 32, "smooth", 11, True),
+        ("s_c3_64x64", 3, True, 8, 2, 64, 64, "uniform", 12, False),
+        ("s_c7_48x80", 7, False, 2, 1, 48, 80, "smooth", 13, False),
+        ("s_c3_128x96", 3, True, 2, 1, 128, 96, "smooth", 14, False),
+    ]
+    for tag, C, ds, wseed, B, H, W, kind, fseed, inter in small:
+        frames = syn.make_frames_u8(B, H, W, kind, fseed)
+        sd, logits, pred, t = run_reference(NestedUNet, syn, C, ds, wseed, frames, inter)
+        payload = dict(num_classes=C, deep_supervision=ds, wseed=wseed, B=B, H=H, W=W, kind=kind, fseed=fseed,
+                       frames_sha=sha(frames), weights_sha=sha(np.concatenate([v.ravel().astype(np.float64) for v in sd.values()])),
+                       logits=logits.astype(np.float32), mask=pred,
+                       mask_cable=(pred == 1).astype(np.uint8), mask_tape=(pred == 2).astype(np.uint8))
+        for k, v in t.items():
+            payload["t_" + k] = v.astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **payload)
+        hist = np.bincount(pred.ravel(), minlength=C).tolist()
+        meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] class_hist={hist} min_margin={margin_of(logits).min():.3e}")
+
+    # ---- full-size cases: mask, subsampled logits, checksums, near-tie pixel list
+    big = [
+        ("b_c3_512x512", 3, True, 2, 2, 512, 512, ("smooth", "uniform"), 1234),
+        ("b_c7_448x800", 7, False, 0, 1, 448, 800, ("smooth",), 1234),
+    ]
+    for tag, C, ds, wseed, B, H, W, kinds, fseed in big:
+        frames = np.stack([syn.make_frame_u8(H, W, i, kinds[i % len(kinds)], fseed) for i in range(B)])
+        sd, logits, pred, _ = run_reference(NestedUNet, syn, C, ds, wseed, frames, False)
+        m = margin_of(logits)
+        tie_idx = np.argwhere(m < 1e-3).astype(np.int32)              # (b, y, x) of near-tie pixels
+        tie_margin = m[m < 1e-3].astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"),
+                            num_classes=C, deep_supervision=ds, wseed=wseed, B=B, H=H, W=W, kinds=np.array(kinds), fseed=fseed,
+                            frames_sha=sha(frames), mask=pred, logits_sub8=logits[:, :, ::8, ::8].astype(np.float32),
+                            logits_sha=sha(logits.astype(np.float32)), mask_sha=sha(pred),
+                            tie_idx=tie_idx, tie_margin=tie_margin,
+                            class_hist=np.stack([np.bincount(pred[i].ravel(), minlength=C) for i in range(B)]))
+        meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] "
+                          f"class_hist={np.bincount(pred.ravel(), minlength=C).tolist()} near_ties(<1e-3)={len(tie_margin)} "
+                          f"min_margin={m.min():.3e}")
+
+    # ---- state_dict manifests (loader tests) for the two constructor variants the callers use
+    manifest = {}
+    for C, ds in ((3, True), (7, False)):
+        model = NestedUNet(num_classes=C, input_channels=3, deep_supervision=ds)
+        manifest[f"c{C}_ds{int(ds)}"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")]
+                                         for k, v in model.state_dict().items()]
+    import json
+    with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0)
+    with open(os.path.join(OUT, "README.txt"), "w") as f:
+        f.write("Golden vectors produced by oracle/make_golden.py from the reference NestedUNet\n"
+                f"(torch {torch.__version__}, {torch.get_num_threads()} threads, CPU fp32) on synthetic weights/frames.\n\n")
+        f.write("\n".join(meta_lines) + "\n")
+    print("\n".join(meta_lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference UNet++ inference hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the
+product (unet-_amd/) never does and fails loudly when its HIP library is missing.
+
+What is restated (citations are /root/reference paths):
+  * ConvBlock.forward           src/models/unetpp.py:23-26   relu(bn1(conv1(x))), relu(bn2(conv2(x)))
+  * NestedUNet.forward (eval)   src/models/unetpp.py:104-119 encoder column + outer decoder diagonal
+  * nn.MaxPool2d(2,2)           src/models/unetpp.py:75
+  * nn.Upsample(2,'bilinear',align_corners=True)  src/models/unetpp.py:76
+  * torch.cat([skip, up],1)     src/models/unetpp.py:112-116  (skip channels first)
+  * final 1x1 conv              src/models/unetpp.py:85,119
+  * softmax -> argmax -> uint8, class masks   infer_two_stage_burr.py:299-304
+
+The arithmetic of conv / batch-norm / bilinear upsampling lives in a third-party dependency of the
+reference, PyTorch (requirements.txt:1 pins only torch>=1.10.0; the container has 2.10.0+rocm7.0).
+Two restatements of its published algorithms are given:
+  numpy_forward   plain NumPy (float32, or float64 for a high-precision cross-check)
+  torch_forward   the same graph through torch.nn.functional CPU ops (what the reference's
+                  --device cpu path actually executes); this one is timed as the cpu_baseline.
+
+PARITY PIN: the reference has no tests, golden vectors or fixtures for this path, so
+the oracle is pinned by outputs of the reference model itself, imported in the build container by
+oracle/make_golden.py and committed under tests/golden/ (tests/test_oracle_golden.py checks both
+restatements against them).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BN_EPS = 1e-5  # nn.BatchNorm2d default, unetpp.py:18,20
+
+BLOCKS = ("conv0_0", "conv1_0", "conv2_0", "conv3_0", "conv4_0", "conv3_1", "conv2_2", "conv1_3", "conv0_4")
+
+
+# ----------------------------------------------------------------------------- NumPy restatement
+def conv3x3_np(x, w, b):
+    """nn.Conv2d(k=3, padding=1, stride=1, bias=True) as cross-correlation (unetpp.py:17,19).
+    x [B,Ci,H,W], w [Co,Ci,3,3], b [Co] -> [B,Co,H,W]; accumulates in x.dtype."""
+    B, Ci, H, W = x.shape
+    Co = w.shape[0]
+    xp = np.zeros((B, Ci, H + 2, W + 2), dtype=x.dtype)
+    xp[:, :, 1:-1, 1:-1] = x
+    out = np.empty((B, Co, H, W), dtype=x.dtype)
+    for n in range(B):
+        acc = np.zeros((Co, H * W), dtype=x.dtype)
+        for dy in range(3):
+            for dx in range(3):
+                patch = np.ascontiguousarray(xp[n, :, dy:dy + H, dx:dx + W]).reshape(Ci, H * W)
+                acc += w[:, :, dy, dx].astype(x.dtype) @ patch
+        out[n] = (acc + b.astype(x.dtype)[:, None]).reshape(Co, H, W)
+    return out
+
+
+def conv1x1_np(x, w, b):
+    """nn.Conv2d(32, C, kernel_size=1) (unetpp.py:85)."""
+    B, Ci, H, W = x.shape
+    wm = w.reshape(w.shape[0], Ci).astype(x.dtype)
+    out = np.einsum("oc,bchw->bohw", wm, x, optimize=True)
+    return out + b.astype(x.dtype)[None, :, None, None]
+
+
+def batchnorm_eval_np(x, gamma, beta, mean, var):
+    """nn.BatchNorm2d in eval mode: (x-mean)/sqrt(var+eps)*gamma+beta."""
+    dt = x.dtype
+    inv = (1.0 / np.sqrt(var.astype(dt) + dt.type(BN_EPS))).astype(dt)
+    return (x - mean.astype(dt)[None, :, None, None]) * (inv * gamma.astype(dt))[None, :, None, None] \
+        + beta.astype(dt)[None, :, None, None]
+
+
+def relu_np(x):
+    return np.maximum(x, 0)
+
+
+def maxpool2x2_np(x):
+    """nn.MaxPool2d(kernel_size=2, stride=2): floor mode, no padding (unetpp.py:75)."""
+    B, C, H, W = x.shape
+    h2, w2 = H // 2, W // 2
+    v = x[:, :, :h2 * 2, :w2 * 2].reshape(B, C, h2, 2, w2, 2)
+    return v.max(axis=(3, 5))
+
+
+def bilinear_axis_tables(n_in: int, n_out: int):
+    """Source indices and weights for align_corners=True (ATen area_pixel_compute_scale /
+    compute_source_index_and_lambda): scale=(in-1)/(out-1) in float32; src=scale*dst;
+    i0=int(src); i1=i0+(i0<in-1); l1=src-i0; l0=1-l1."""
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    src = scale * np.arange(n_out, dtype=np.float32)
+    i0 = src.astype(np.int64)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = np.clip(src - i0.astype(np.float32), 0, 1).astype(np.float32)
+    l0 = (np.float32(1) - l1).astype(np.float32)
+    return i0, i1, l0, l1
+
+
+def upsample2x_bilinear_ac_np(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unetpp.py:76).
+    Interpolates along x inside each source row, then between the two rows."""
+    B, C, H, W = x.shape
+    dt = x.dtype
+    y0, y1, ly0, ly1 = bilinear_axis_tables(H, 2 * H)
+    x0, x1, lx0, lx1 = bilinear_axis_tables(W, 2 * W)
+    lx0 = lx0.astype(dt)[None, None, None, :]; lx1 = lx1.astype(dt)[None, None, None, :]
+    ly0 = ly0.astype(dt)[None, None, :, None]; ly1 = ly1.astype(dt)[None, None, :, None]
+    top = x[:, :, y0][:, :, :, x0] * lx0 + x[:, :, y0][:, :, :, x1] * lx1
+    bot = x[:, :, y1][:, :, :, x0] * lx0 + x[:, :, y1][:, :, :, x1] * lx1
+    return top * ly0 + bot * ly1
+
+
+def conv_block_np(x, sd, name):
+    """ConvBlock.forward (unetpp.py:23-26)."""
+    for j in (1, 2):
+        x = conv3x3_np(x, sd[f"{name}.conv{j}.weight"], sd[f"{name}.conv{j}.bias"])
+        x = batchnorm_eval_np(x, sd[f"{name}.bn{j}.weight"], sd[f"{name}.bn{j}.bias"],
+                              sd[f"{name}.bn{j}.running_mean"], sd[f"{name}.bn{j}.running_var"])
+        x = relu_np(x)
+    return x
+
+
+def numpy_forward(sd: dict, x: np.ndarray, dtype=np.float32, return_intermediates: bool = False):
+    """NestedUNet.forward in eval mode (unetpp.py:104-119). x [B,3,H,W] in [0,1] -> logits [B,C,H,W]."""
+    if x.shape[2] % 16 or x.shape[3] % 16:
+        # the reference raises inside torch.cat for such sizes (SURVEY.md §7 hard part 7)
+        raise RuntimeError("Sizes of tensors must match: H and W must be multiples of 16")
+    x = x.astype(dtype)
+    t = {}
+    t["x0_0"] = conv_block_np(x, sd, "conv0_0")
+    t["x1_0"] = conv_block_np(maxpool2x2_np(t["x0_0"]), sd, "conv1_0")
+    t["x2_0"] = conv_block_np(maxpool2x2_np(t["x1_0"]), sd, "conv2_0")
+    t["x3_0"] = conv_block_np(maxpool2x2_np(t["x2_0"]), sd, "conv3_0")
+    t["x4_0"] = conv_block_np(maxpool2x2_np(t["x3_0"]), sd, "conv4_0")
+    cat = np.concatenate
+    t["x3_1"] = conv_block_np(cat([t["x3_0"], upsample2x_bilinear_ac_np(t["x4_0"])], 1), sd, "conv3_1")
+    t["x2_2"] = conv_block_np(cat([t["x2_0"], upsample2x_bilinear_ac_np(t["x3_1"])], 1), sd, "conv2_2")
+    t["x1_3"] = conv_block_np(cat([t["x1_0"], upsample2x_bilinear_ac_np(t["x2_2"])], 1), sd, "conv1_3")
+    t["x0_4"] = conv_block_np(cat([t["x0_0"], upsample2x_bilinear_ac_np(t["x1_3"])], 1), sd, "conv0_4")
+    logits = conv1x1_np(t["x0_4"], sd["final.weight"], sd["final.bias"])
+    if return_intermediates:
+        t["logits"] = logits
+        return logits, t
+    return logits
+
+
+def softmax_np(logits, axis=1):
+    m = logits.max(axis=axis, keepdims=True)
+    e = np.exp(logits - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def masks_from_logits(logits: np.ndarray):
+    """infer_two_stage_burr.py:299-304: softmax(dim=1) -> np.argmax (first max index) -> uint8;
+    mask_cable=(pred==1), mask_tape=(pred==2) as uint8.  softmax is monotone, so argmax of the
+    probabilities equals argmax of the logits except where exp() rounds two different logits to the
+    same probability; the probabilities are used here, as the reference does."""
+    probs = softmax_np(logits.astype(np.float32), axis=1)
+    pred = np.argmax(probs, axis=1).astype(np.uint8)
+    return pred, (pred == 1).astype(np.uint8), (pred == 2).astype(np.uint8)
+
+
+def top2_margin(logits: np.ndarray) -> np.ndarray:
+    """Per-pixel gap between the largest and second-largest logit (for margin-aware flip accounting)."""
+    s = np.sort(logits, axis=1)
+    return (s[:, -1] - s[:, -2]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- torch CPU restatement
+def torch_forward(sd: dict, x, return_intermediates: bool = False):
+    """Same graph through torch.nn.functional on the CPU (fp32) — the ops the reference's
+    `--device cpu` path dispatches to.  sd values may be numpy arrays or torch tensors."""
+    import torch
+    import torch.nn.functional as F
+
+    def T(a):
+        return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+
+    x = T(x).float()
+    if x.shape[2] % 16 or x.shape[3] % 16:
+        raise RuntimeError("Sizes of tensors must match: H and W must be multiples of 16")
+
+    def block(x, name):
+        for j in (1, 2):
+            x = F.conv2d(x, T(sd[f"{name}.conv{j}.weight"]), T(sd[f"{name}.conv{j}.bias"]), padding=1)
+            x = F.batch_norm(x, T(sd[f"{name}.bn{j}.running_mean"]), T(sd[f"{name}.bn{j}.running_var"]),
+                             T(sd[f"{name}.bn{j}.weight"]), T(sd[f"{name}.bn{j}.bias"]), False, 0.1, BN_EPS)
+            x = F.relu(x)
+        return x
+
+    def up(x):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+    def pool(x):
+        return F.max_pool2d(x, 2, 2)
+
+    with torch.no_grad():
+        t = {}
+        t["x0_0"] = block(x, "conv0_0")
+        t["x1_0"] = block(pool(t["x0_0"]), "conv1_0")
+        t["x2_0"] = block(pool(t["x1_0"]), "conv2_0")
+        t["x3_0"] = block(pool(t["x2_0"]), "conv3_0")
+        t["x4_0"] = block(pool(t["x3_0"]), "conv4_0")
+        t["x3_1"] = block(torch.cat([t["x3_0"], up(t["x4_0"])], 1), "conv3_1")
+        t["x2_2"] = block(torch.cat([t["x2_0"], up(t["x3_1"])], 1), "conv2_2")
+        t["x1_3"] = block(torch.cat([t["x1_0"], up(t["x2_2"])], 1), "conv1_3")
+        t["x0_4"] = block(torch.cat([t["x0_0"], up(t["x1_3"])], 1), "conv0_4")
+        logits = F.conv2d(t["x0_4"], T(sd["final.weight"]), T(sd["final.bias"]))
+    if return_intermediates:
+        t["logits"] = logits
+        return logits.numpy(), {k: v.numpy() for k, v in t.items()}
+    return logits.numpy()
+
+
+def torch_segment(sd: dict, x):
+    """Frame-loop tail (infer_two_stage_burr.py:294-300) on the CPU: logits -> softmax -> argmax -> uint8."""
+    import torch
+    logits = torch.from_numpy(torch_forward(sd, x))
+    probs = torch.softmax(logits, dim=1).numpy()
+    return np.argmax(probs, axis=1).astype(np.uint8)

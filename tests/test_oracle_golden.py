@@ -1,0 +1,97 @@
+"""Pins the oracle (oracle/unetpp_oracle.py) to the reference: every committed golden vector was
+produced by the reference NestedUNet itself (oracle/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+SMALL = ["s_c3_32x32", "s_c3_64x64", "s_c7_48x80", "s_c3_128x96"]
+
+
+def _inputs(syn, g):
+    frames = syn.make_frames_u8(int(g["B"]), int(g["H"]), int(g["W"]), str(g["kind"]), int(g["fseed"]))
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha"])
+    sd = syn.make_state_dict(int(g["num_classes"]), 3, bool(g["deep_supervision"]), int(g["wseed"]))
+    return sd, syn.frames_to_chw_f32(frames)
+
+
+@pytest.mark.parametrize("tag", SMALL)
+def test_torch_restatement_matches_reference(tag, oracle, syn):
+    g = load_golden(tag)
+    sd, x = _inputs(syn, g)
+    logits = oracle.torch_forward(sd, x)
+    # same ops, same library: equal to a few ulp (thread count may differ from the generating run)
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-6)
+    pred, cable, tape = oracle.masks_from_logits(logits)
+    assert np.array_equal(pred, g["mask"])
+    assert np.array_equal(cable, g["mask_cable"]) and np.array_equal(tape, g["mask_tape"])
+
+
+@pytest.mark.parametrize("tag", SMALL[:3])
+def test_numpy_restatement_matches_reference(tag, oracle, syn):
+    g = load_golden(tag)
+    sd, x = _inputs(syn, g)
+    logits = oracle.numpy_forward(sd, x, dtype=np.float32)
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-5)
+    pred, _, _ = oracle.masks_from_logits(logits)
+    margin = oracle.top2_margin(g["logits"])
+    differs = pred != g["mask"]
+    assert not differs[margin > 1e-4].any()
+
+
+def test_numpy_fp64_restatement(oracle, syn):
+    g = load_golden("s_c3_32x32")
+    sd, x = _inputs(syn, g)
+    logits = oracle.numpy_forward(sd, x, dtype=np.float64)
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=5e-6)
+
+
+def test_intermediates_match_reference(oracle, syn):
+    g = load_golden("s_c3_32x32")
+    sd, x = _inputs(syn, g)
+    _, t_np = oracle.numpy_forward(sd, x, return_intermediates=True)
+    _, t_th = oracle.torch_forward(sd, x, return_intermediates=True)
+    for name in ("x0_0", "x1_0", "x2_0", "x3_0", "x4_0", "x3_1", "x2_2", "x1_3", "x0_4"):
+        ref = g["t_" + name]
+        np.testing.assert_allclose(t_th[name], ref, rtol=0, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(t_np[name], ref, rtol=0, atol=3e-5, err_msg=name)
+
+
+def test_full_size_golden_512(oracle, syn):
+    g = load_golden("b_c3_512x512")
+    kinds = [str(k) for k in g["kinds"]]
+    frames = np.stack([syn.make_frame_u8(512, 512, i, kinds[i % len(kinds)], int(g["fseed"])) for i in range(int(g["B"]))])
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha"])
+    sd = syn.make_state_dict(3, 3, True, int(g["wseed"]))
+    logits = oracle.torch_forward(sd, syn.frames_to_chw_f32(frames))
+    np.testing.assert_allclose(logits[:, :, ::8, ::8], g["logits_sub8"], rtol=0, atol=5e-6)
+    pred, _, _ = oracle.masks_from_logits(logits)
+    diff = np.argwhere(pred != g["mask"])
+    ties = {tuple(t) for t in g["tie_idx"].tolist()}
+    assert all(tuple(d) in ties for d in diff.tolist())     # only near-tie pixels may differ
+    assert len(diff) <= 2
+
+
+def test_edge_cases(oracle, syn):
+    sd = syn.make_state_dict(3, 3, True, 2)
+    with pytest.raises(RuntimeError):                         # reference raises in torch.cat
+        oracle.numpy_forward(sd, np.zeros((1, 3, 100, 100), np.float32))
+    with pytest.raises(RuntimeError):
+        oracle.torch_forward(sd, np.zeros((1, 3, 24, 32), np.float32))
+    # batch-row invariance: frame i of a batch equals the same frame alone
+    x = syn.frames_to_chw_f32(syn.make_frames_u8(3, 32, 48, "uniform", 5))
+    full = oracle.torch_forward(sd, x)
+    one = oracle.torch_forward(sd, x[1:2])
+    np.testing.assert_allclose(full[1:2], one, rtol=0, atol=1e-5)
+    # argmax tie rule: first maximal index (np.argmax, infer_two_stage_burr.py:300)
+    lg = np.zeros((1, 3, 2, 2), np.float32)
+    pred, cable, tape = oracle.masks_from_logits(lg)
+    assert (pred == 0).all() and cable.sum() == 0 and tape.sum() == 0
+
+
+def test_bilinear_tables(oracle):
+    i0, i1, l0, l1 = oracle.bilinear_axis_tables(4, 8)
+    assert i0[0] == 0 and l1[0] == 0 and i0[-1] == 3 and i1[-1] == 3     # corners align, last clamps
+    assert np.allclose(l0 + l1, 1)
