@@ -1,0 +1,123 @@
+/* unetpp.h — C ABI of the MI355X-native UNet++ (NestedUNet) inference engine.
+ *
+ * The reference (Chenxu1103/UNET-) is pure Python and has no FFI of its own; the boundary this
+ * library replaces is the nn.Module protocol exercised by its frame loops.  Each entry point cites
+ * the reference interface it stands in for (paths relative to the reference root).  The Python
+ * drop-in (unet-_amd/nested_unet.py) binds exactly these symbols with ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative UNETPP_E_* code; the message is
+ * available from unetpp_last_error().  All pointers named dev_* are HIP device pointers on the
+ * engine's device; `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ * unetpp_forward() is asynchronous on `stream` and never synchronises.  One engine per device;
+ * an engine is not thread-safe, independent engines are.  The caller owns all I/O buffers; the
+ * library owns packed weights and the activation workspace and never keeps a caller pointer.
+ */
+#ifndef UNETPP_H
+#define UNETPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct unetpp_engine unetpp_engine;
+
+enum {
+  UNETPP_OK = 0,
+  UNETPP_E_INVALID = -1,     /* bad argument (shape not a multiple of 16, batch too large, ...) */
+  UNETPP_E_UNSUPPORTED = -2, /* e.g. pretrained_encoder=True (src/models/unetpp.py:52-65) */
+  UNETPP_E_HIP = -3,         /* a HIP runtime call failed */
+  UNETPP_E_STATE = -4        /* forward before weights were loaded, ... */
+};
+
+/* precision of the 3x3-conv stacks (the 1x1 head always runs in fp32):
+ *   EXACT  fp16 MFMA with split operands (x = hi + lo for activations and weights, three MFMAs per
+ *          product, fp32 accumulate): fp32-class accuracy; this is the parity-gated mode.
+ *   FAST   plain fp16 operands, fp32 accumulate: single MFMA per product.                      */
+enum { UNETPP_PREC_EXACT = 0, UNETPP_PREC_FAST = 1 };
+
+/* input formats accepted by unetpp_forward */
+enum {
+  UNETPP_IN_F32_NCHW = 0,    /* float32 [B,3,H,W] RGB in [0,1]: the tensor model(img_tensor) receives,
+                                infer_two_stage_burr.py:292-295 */
+  UNETPP_IN_U8_NHWC_BGR = 1  /* uint8 [B,H,W,3] BGR frame at model resolution: fuses the resize-free
+                                part of preprocess_image (BGR->RGB, /255, HWC->CHW),
+                                infer_two_stage_burr.py:122-127 */
+};
+
+typedef struct unetpp_config {
+  int num_classes;   /* NestedUNet(num_classes=...)            src/models/unetpp.py:42 */
+  int in_channels;   /* NestedUNet(input_channels=3)           src/models/unetpp.py:43 (only 3 supported) */
+  int max_batch;     /* largest B passed to unetpp_forward */
+  int max_h;         /* largest H (multiple of 16) */
+  int max_w;         /* largest W (multiple of 16) */
+  int precision;     /* UNETPP_PREC_* */
+  int device;        /* HIP device ordinal: model.to(device)   infer_two_stage_burr.py:214 */
+  int micro_batch;   /* frames pushed through the network per pass (0 = max_batch) */
+} unetpp_config;
+
+/* NestedUNet.__init__ + .to(device) (src/models/unetpp.py:40-91, infer_two_stage_burr.py:214):
+ * allocates the activation workspace for (micro_batch, max_h, max_w) on cfg->device. */
+int unetpp_create(const unetpp_config* cfg, unetpp_engine** out);
+
+/* del model */
+void unetpp_destroy(unetpp_engine* e);
+
+/* Text of the last error on this engine (or, with e == NULL, of the last failed unetpp_create). */
+const char* unetpp_last_error(const unetpp_engine* e);
+
+const char* unetpp_version(void);
+
+/* Size in bytes of the canonical weight blob for a (num_classes, in_channels) network:
+ * 32-byte header {magic 'UNPP', version, num_classes, in_channels, n_convs, 0,0,0} followed, for
+ * each of the 18 3x3 convs in forward order (conv0_0.conv1, conv0_0.conv2, conv1_0.conv1, ...,
+ * conv0_4.conv2) and then the 1x1 head, by the BN-folded fp32 weight in OIHW order and the
+ * folded fp32 bias.  The host side (unet-_amd/packing.py) builds it from a state_dict. */
+size_t unetpp_weights_blob_bytes(int num_classes, int in_channels);
+
+/* model.load_state_dict(checkpoint['model'], strict=True) (infer_two_stage_burr.py:215-216):
+ * takes the canonical blob from host memory, uploads it and repacks it on the device into the
+ * kernels' layouts (per-channel power-of-two scaling, fp16 hi/lo planes, tile order). Synchronous. */
+int unetpp_load_weights(unetpp_engine* e, const void* host_blob, size_t bytes);
+
+/* Same, from a blob already in device memory (e.g. after the RCCL broadcast from rank 0);
+ * asynchronous on `stream`. */
+int unetpp_load_weights_device(unetpp_engine* e, const void* dev_blob, size_t bytes, void* stream);
+
+/* outputs = model(img_tensor); probs = softmax(outputs,1); pred = argmax(probs,0).astype(uint8);
+ * mask_cable = (pred==1); mask_tape = (pred==2)        (infer_two_stage_burr.py:294-304).
+ *   dev_input   B frames in `in_format`
+ *   dev_logits  float32 [B,num_classes,H,W] or NULL      (NestedUNet.forward return, unetpp.py:119,135)
+ *   dev_mask    uint8 [B,H,W] class index (first maximal class) or NULL
+ *   dev_cable / dev_tape  uint8 [B,H,W] 0/1 masks of class 1 / class 2, or NULL
+ * H and W must be multiples of 16 (the reference raises in torch.cat otherwise), B <= max_batch. */
+int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w,
+                   float* dev_logits, uint8_t* dev_mask, uint8_t* dev_cable, uint8_t* dev_tape,
+                   void* stream);
+
+/* Bytes of device memory held by the engine (workspace + packed weights). */
+size_t unetpp_workspace_bytes(const unetpp_engine* e);
+
+/* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------
+ * With profiling on, every kernel launch of the next forward is bracketed by HIP events recorded
+ * on the launch stream.  unetpp_profile_read synchronises those events and returns, per launch in
+ * issue order, its duration in milliseconds; unetpp_profile_name gives the launch's label. */
+int unetpp_profile_enable(unetpp_engine* e, int on);
+int unetpp_profile_count(const unetpp_engine* e);
+int unetpp_profile_read(unetpp_engine* e, float* ms_out, int n);
+const char* unetpp_profile_name(const unetpp_engine* e, int i);
+/* algorithmic FLOPs and minimum HBM bytes (read+write) of launch i for the last forward's shape */
+int unetpp_profile_work(const unetpp_engine* e, int i, double* flops, double* bytes);
+
+/* ---- debug (layer-by-layer parity tests) -------------------------------------------------------
+ * Copies the named activation of the LAST micro-batch processed ("x0_0", "x1_0", ..., "x0_4") to
+ * host memory as float32 [b,C,h,w]; returns the number of floats written or a negative error. */
+long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out, size_t max_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETPP_H */

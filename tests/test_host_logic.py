@@ -1,0 +1,100 @@
+"""CPU-side checks: ABI library loads and exports every declared symbol, BN folding, strict
+state-dict checking, blob layout.  No compute call is made (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_builds_and_exports_all_symbols():
+    from unet_amd import _lib
+    path = _lib.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "unetpp.h")).read()
+    declared = set(re.findall(r"\b(unetpp_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.ABI_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.unetpp_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.unetpp_version()
+
+
+def test_blob_size_matches_abi(syn):
+    from unet_amd import _lib, packing
+    lib = _lib.load()
+    for C, ds in ((3, True), (7, False)):
+        sd = syn.make_state_dict(C, 3, ds, 0)
+        blob = packing.build_blob(sd, C)
+        assert blob.nbytes == lib.unetpp_weights_blob_bytes(C, 3)
+        hdr = blob[:32].view(np.uint32)
+        assert hdr[0] == packing.BLOB_MAGIC and hdr[2] == C and hdr[4] == 19
+    # 7,846,723 folded conv weights+biases for the 3-class net
+    assert (lib.unetpp_weights_blob_bytes(3, 3) - 32) // 4 == 7846723
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from unet_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.Config(3, 3, 1, 32, 32, 0, 0, 0)
+    h = ctypes.c_void_p()
+    rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc != 0 and not h.value
+    assert b"no CPU fallback" in lib.unetpp_last_error(None) or b"HIP" in lib.unetpp_last_error(None)
+    from unet_amd.nested_unet import NestedUNet
+    with pytest.raises(RuntimeError):
+        NestedUNet(3).to("cpu")
+
+
+def test_bn_fold_equals_conv_bn(syn, oracle):
+    from unet_amd import packing
+    sd = syn.make_state_dict(3, 3, True, 5)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 32, 12, 10)).astype(np.float64)
+    name = "conv1_0"
+    ref = oracle.conv3x3_np(x, sd[f"{name}.conv1.weight"].astype(np.float64), sd[f"{name}.conv1.bias"].astype(np.float64))
+    ref = oracle.batchnorm_eval_np(ref, sd[f"{name}.bn1.weight"], sd[f"{name}.bn1.bias"], sd[f"{name}.bn1.running_mean"], sd[f"{name}.bn1.running_var"])
+    wf, bf = packing.fold_conv_bn(sd[f"{name}.conv1.weight"], sd[f"{name}.conv1.bias"], sd[f"{name}.bn1.weight"],
+                                  sd[f"{name}.bn1.bias"], sd[f"{name}.bn1.running_mean"], sd[f"{name}.bn1.running_var"])
+    got = oracle.conv3x3_np(x, wf.astype(np.float64), bf.astype(np.float64))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_strict_state_dict_checks(syn):
+    from unet_amd import packing
+    sd = syn.make_state_dict(3, 3, True, 0)
+    assert packing.check_state_dict(sd, 3, 3, True, strict=True) == ([], [])
+    extra = dict(sd); extra["bogus.weight"] = np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        packing.check_state_dict(extra, 3, 3, True, strict=True)
+    assert packing.check_state_dict(extra, 3, 3, True, strict=False) == ([], ["bogus.weight"])
+    # a deep_supervision=True checkpoint loaded into a ds=False model: ds heads are unexpected (strict)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        packing.check_state_dict(sd, 3, 3, False, strict=True)
+    assert packing.unwrap_checkpoint({"model": sd, "epoch": 3}) is sd
+    assert packing.unwrap_checkpoint({"model_state_dict": sd}) is sd
+    assert packing.infer_num_classes(sd) == 3
+
+
+def test_manifest_matches_reference_fixture(syn):
+    import json
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))
+    for key, (C, ds) in (("c3_ds1", (3, True)), ("c7_ds0", (7, False))):
+        mine = [[k, list(s), d] for k, s, d in syn.state_dict_manifest(C, 3, ds)]
+        assert mine == man[key]
+        assert len(mine) == (134 if ds else 128)
+
+
+def test_frame_preprocess_matches_reference_semantics(syn):
+    from unet_amd.frame_loop import preprocess_frames
+    f = syn.make_frames_u8(2, 16, 32, "uniform", 9)
+    x = preprocess_frames(f)
+    assert x.shape == (2, 3, 16, 32) and x.dtype == np.float32
+    assert x[1, 0, 3, 5] == np.float32(f[1, 3, 5, 2]) / np.float32(255.0)      # R plane comes from BGR index 2
+    assert np.array_equal(x, syn.frames_to_chw_f32(f))

@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI declared in include/unetpp.h, plus the in-tree build of the HIP library.
+
+The product path has no CPU fallback: if libunetpp_hip.so is missing or cannot be loaded, or no HIP
+device is present, every entry point raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunetpp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["unetpp_abi.hip"]
+HEADERS = ["conv3x3_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include", "unetpp.h")]
+
+# every symbol include/unetpp.h declares
+ABI_SYMBOLS = [
+    "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
+    "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_workspace_bytes",
+    "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
+    "unetpp_profile_work", "unetpp_debug_read",
+]
+
+PREC_EXACT, PREC_FAST = 0, 1
+IN_F32_NCHW, IN_U8_NHWC_BGR = 0, 1
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("num_classes", ctypes.c_int), ("in_channels", ctypes.c_int), ("max_batch", ctypes.c_int),
+                ("max_h", ctypes.c_int), ("max_w", ctypes.c_int), ("precision", ctypes.c_int),
+                ("device", ctypes.c_int), ("micro_batch", ctypes.c_int)]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> unet-_amd/libunetpp_hip.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.unetpp_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]; lib.unetpp_create.restype = ci
+    lib.unetpp_destroy.argtypes = [vp]; lib.unetpp_destroy.restype = None
+    lib.unetpp_last_error.argtypes = [vp]; lib.unetpp_last_error.restype = ctypes.c_char_p
+    lib.unetpp_version.argtypes = []; lib.unetpp_version.restype = ctypes.c_char_p
+    lib.unetpp_weights_blob_bytes.argtypes = [ci, ci]; lib.unetpp_weights_blob_bytes.restype = cs
+    lib.unetpp_load_weights.argtypes = [vp, vp, cs]; lib.unetpp_load_weights.restype = ci
+    lib.unetpp_load_weights_device.argtypes = [vp, vp, cs, vp]; lib.unetpp_load_weights_device.restype = ci
+    lib.unetpp_forward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]; lib.unetpp_forward.restype = ci
+    lib.unetpp_workspace_bytes.argtypes = [vp]; lib.unetpp_workspace_bytes.restype = cs
+    lib.unetpp_profile_enable.argtypes = [vp, ci]; lib.unetpp_profile_enable.restype = ci
+    lib.unetpp_profile_count.argtypes = [vp]; lib.unetpp_profile_count.restype = ci
+    lib.unetpp_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ci]; lib.unetpp_profile_read.restype = ci
+    lib.unetpp_profile_name.argtypes = [vp, ci]; lib.unetpp_profile_name.restype = ctypes.c_char_p
+    lib.unetpp_profile_work.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.unetpp_profile_work.restype = ci
+    lib.unetpp_debug_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), cs]
+    lib.unetpp_debug_read.restype = ctypes.c_longlong
+    _lib = lib
+    return lib

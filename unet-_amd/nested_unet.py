@@ -1,0 +1,237 @@
+"""Drop-in for the reference's ``NestedUNet`` (src/models/unetpp.py:28-135) in inference use.
+
+Same constructor keywords, the nn.Module surface the frame loops touch (``.to``, ``.eval``,
+``.load_state_dict``, ``__call__``) and the same results; the work is done by hand-written HIP
+kernels behind the C ABI of include/unetpp.h.  PyTorch tensors are only I/O buffers (``data_ptr()``)
+and the source of the current HIP stream — no torch op runs on the hot path.
+
+    model = NestedUNet(num_classes=3, deep_supervision=True, pretrained_encoder=False).to(device)   # infer_two_stage_burr.py:214
+    model.load_state_dict(checkpoint['model'], strict=True); model.eval()                           # :215-217
+    outputs = model(img_tensor)                                                                      # :294-297
+    pred = model.segment(img_tensor)       # fused replacement of :294-300 (uint8 class-index mask, on device)
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib, packing
+
+
+class NestedUNet:
+    def __init__(self, num_classes: int, input_channels: int = 3, deep_supervision: bool = True,
+                 pretrained_encoder: bool = False, *, precision: str = "exact", max_batch: int = 16,
+                 max_hw=(512, 512), micro_batch: int = 0) -> None:
+        if pretrained_encoder:
+            # unetpp.py:52-65 swaps in a torchvision ResNet50 and downloads ImageNet weights; no
+            # north-star caller uses it (infer_two_stage_burr.py:214) and there is no network here.
+            raise NotImplementedError("pretrained_encoder=True is unsupported by the MI355X engine")
+        if input_channels != 3:
+            raise NotImplementedError("input_channels must be 3")
+        if precision not in ("exact", "fast"):
+            raise ValueError("precision must be 'exact' or 'fast'")
+        self.num_classes = int(num_classes)
+        self.input_channels = int(input_channels)
+        self.deep_supervision = bool(deep_supervision)
+        self.training = False
+        self.precision = precision
+        self._max_batch = int(max_batch)
+        self._max_hw = (int(max_hw[0]), int(max_hw[1]))
+        self._micro_batch = int(micro_batch)
+        self._device_index: Optional[int] = None
+        self._handle = None
+        self._blob: Optional[np.ndarray] = None      # canonical weights (host copy, re-uploaded if the engine is rebuilt)
+        self._state_dict = None
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def to(self, device):
+        import torch
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"device '{dev}': the MI355X engine runs on HIP devices only (no CPU fallback); "
+                               "use the reference model for --device cpu")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._device_index is not None and idx != self._device_index:
+            self._destroy()
+        self._device_index = idx
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else f"cuda:{device}")
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("inference-only engine: train() is unsupported")
+        return self.eval()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        state_dict = packing.unwrap_checkpoint(state_dict)
+        missing, unexpected = packing.check_state_dict(state_dict, self.num_classes, self.input_channels,
+                                                       self.deep_supervision, strict)
+        if missing:
+            raise RuntimeError("Missing key(s) in state_dict: " + ", ".join(missing))
+        self._blob = packing.build_blob(state_dict, self.num_classes, self.input_channels)
+        self._state_dict = {k: packing._np(v).copy() for k, v in state_dict.items()}
+        if self._handle is not None:
+            self._upload()
+        return missing, unexpected
+
+    def state_dict(self):
+        if self._state_dict is None:
+            raise RuntimeError("no weights loaded")
+        return dict(self._state_dict)
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    # ------------------------------------------------------------------ engine management
+    def _err(self, rc: int) -> str:
+        lib = _lib.load()
+        msg = lib.unetpp_last_error(self._handle)
+        return f"unetpp error {rc}: {msg.decode() if msg else ''}"
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.load().unetpp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _ensure_engine(self, b: int, h: int, w: int):
+        if self._device_index is None:
+            raise RuntimeError("call .to('cuda:N') first: the MI355X engine has no CPU path")
+        grow = (self._handle is None or b > self._max_batch or h > self._max_hw[0] or w > self._max_hw[1])
+        if not grow:
+            return
+        self._destroy()
+        self._max_batch = max(self._max_batch, b)
+        self._max_hw = (max(self._max_hw[0], h), max(self._max_hw[1], w))
+        lib = _lib.load()
+        cfg = _lib.Config(self.num_classes, self.input_channels, self._max_batch, self._max_hw[0], self._max_hw[1],
+                          _lib.PREC_EXACT if self.precision == "exact" else _lib.PREC_FAST, self._device_index,
+                          self._micro_batch)
+        handle = ctypes.c_void_p()
+        rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(handle))
+        if rc != 0:
+            msg = lib.unetpp_last_error(None)
+            raise RuntimeError(f"unetpp_create failed ({rc}): {msg.decode() if msg else ''}")
+        self._handle = handle
+        if self._blob is not None:
+            self._upload()
+
+    def _upload(self):
+        lib = _lib.load()
+        rc = lib.unetpp_load_weights(self._handle, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.nbytes)
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+
+    def load_weights_from_device_blob(self, blob_tensor):
+        """After an RCCL broadcast: `blob_tensor` is a uint8 CUDA tensor holding the canonical blob."""
+        import torch
+        self._ensure_engine(1, 16, 16)
+        rc = _lib.load().unetpp_load_weights_device(self._handle, ctypes.c_void_p(blob_tensor.data_ptr()),
+                                                    blob_tensor.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        self._blob = blob_tensor.cpu().numpy()
+
+    # ------------------------------------------------------------------ the hot path
+    def _run(self, x, want_logits: bool, want_mask: bool, want_class_masks: bool):
+        import torch
+        if self.training:
+            raise RuntimeError("engine is inference-only")
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError("input must be a CUDA (HIP) tensor on the engine's device")
+        if self._blob is None:
+            raise RuntimeError("load_state_dict() must be called before forward")
+        if x.dtype == torch.float32:
+            if x.dim() != 4 or x.shape[1] != self.input_channels:
+                raise RuntimeError(f"expected input [B,{self.input_channels},H,W], got {tuple(x.shape)}")
+            b, _, h, w = x.shape
+            fmt = _lib.IN_F32_NCHW
+        elif x.dtype == torch.uint8:
+            if x.dim() != 4 or x.shape[3] != 3:
+                raise RuntimeError(f"expected uint8 frames [B,H,W,3] (BGR), got {tuple(x.shape)}")
+            b, h, w, _ = x.shape
+            fmt = _lib.IN_U8_NHWC_BGR
+        else:
+            raise RuntimeError(f"unsupported input dtype {x.dtype}")
+        if h % 16 or w % 16:
+            # same failure the reference hits inside torch.cat (unetpp.py:112-116) for such sizes
+            raise RuntimeError(f"Sizes of tensors must match: H={h}, W={w} must be multiples of 16")
+        if self._device_index is None:
+            self.to(x.device)
+        if x.device.index != self._device_index:
+            raise RuntimeError(f"input on {x.device}, engine on cuda:{self._device_index}")
+        x = x.contiguous()
+        self._ensure_engine(b, h, w)
+        dev = x.device
+        logits = torch.empty((b, self.num_classes, h, w), dtype=torch.float32, device=dev) if want_logits else None
+        mask = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_mask else None
+        cable = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_class_masks else None
+        tape = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_class_masks else None
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = _lib.load().unetpp_forward(self._handle, p(x), fmt, b, h, w, p(logits), p(mask), p(cable), p(tape), stream)
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        return logits, mask, cable, tape
+
+    def forward(self, x):
+        """NestedUNet.forward in eval mode (unetpp.py:93-135): float32 [B,3,H,W] -> float32 logits [B,C,H,W]."""
+        return self._run(x, True, False, False)[0]
+
+    def segment(self, x, return_logits: bool = False, return_class_masks: bool = False):
+        """Fused model call + softmax/argmax/uint8 (+ class masks) of infer_two_stage_burr.py:294-304.
+        x: float32 [B,3,H,W] in [0,1] or uint8 [B,H,W,3] BGR frames at model resolution."""
+        logits, mask, cable, tape = self._run(x, return_logits, True, return_class_masks)
+        out = (mask,)
+        if return_class_masks:
+            out += (cable, tape)
+        if return_logits:
+            out += (logits,)
+        return out[0] if len(out) == 1 else out
+
+    # ------------------------------------------------------------------ measurement / debug hooks
+    def workspace_bytes(self) -> int:
+        return int(_lib.load().unetpp_workspace_bytes(self._handle)) if self._handle else 0
+
+    def profile(self, on: bool = True):
+        _lib.load().unetpp_profile_enable(self._handle, 1 if on else 0)
+
+    def profile_read(self):
+        """[(launch name, ms, algorithmic flops, min HBM bytes)] of the last forward (profiling on)."""
+        lib = _lib.load()
+        n = lib.unetpp_profile_count(self._handle)
+        ms = (ctypes.c_float * max(n, 1))()
+        got = lib.unetpp_profile_read(self._handle, ms, n)
+        if got < 0:
+            raise RuntimeError(self._err(got))
+        out = []
+        for i in range(got):
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            lib.unetpp_profile_work(self._handle, i, ctypes.byref(fl), ctypes.byref(by))
+            out.append((lib.unetpp_profile_name(self._handle, i).decode(), float(ms[i]), fl.value, by.value))
+        return out
+
+    def debug_activation(self, name: str, b: int, h: int, w: int) -> np.ndarray:
+        """float32 [b,C,h',w'] copy of an intermediate node ('x0_0'..'x4_0','x3_1','x2_2','x1_3','x0_4')."""
+        lvl = int(name[1])
+        c = (32, 64, 128, 256, 512)[lvl]
+        out = np.empty((b, c, h >> lvl, w >> lvl), dtype=np.float32)
+        n = _lib.load().unetpp_debug_read(self._handle, name.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), out.size)
+        if n < 0:
+            raise RuntimeError(self._err(int(n)))
+        if n != out.size:
+            raise RuntimeError(f"debug_read returned {n} floats, expected {out.size}")
+        return out

@@ -1,0 +1,57 @@
+"""Multi-GPU: frames are independent, so the path shards batch-wise with full weight replicas.
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).  The only collective is
+the init-time broadcast of the canonical weight blob from rank 0 over xGMI; there is no steady-state
+exchange (optionally an all_gather of uint8 masks when one rank must own every output).
+The reference has no distributed code at all; this is an addition, not a port.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous slice [lo, hi) of `total` frames owned by `rank` (earlier ranks take the remainder)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_blob(blob_np, nbytes: int, device, src: int = 0):
+    """Broadcast the canonical weight blob (uint8) from `src`; returns a uint8 tensor on `device`.
+    Ranks other than src pass blob_np=None."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(blob_np)).to(device)
+        assert t.numel() == nbytes
+    else:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return t
+
+
+def load_replicated(model, state_dict_or_none, num_classes: int, in_channels: int = 3, src: int = 0):
+    """Rank `src` folds/packs its state_dict; every rank receives the blob by broadcast and uploads it
+    with unetpp_load_weights_device (no host round trip on the receivers)."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib, packing
+    nbytes = int(_lib.load().unetpp_weights_blob_bytes(num_classes, in_channels))
+    blob = None
+    if dist.get_rank() == src:
+        sd = packing.unwrap_checkpoint(state_dict_or_none)
+        packing.check_state_dict(sd, num_classes, in_channels, model.deep_supervision, strict=True)
+        blob = packing.build_blob(sd, num_classes, in_channels)
+    dev = torch.device(f"cuda:{model._device_index}")
+    t = broadcast_blob(blob, nbytes, dev, src)
+    model.load_weights_from_device_blob(t)
+    return t
+
+
+def gather_masks(local_mask, world: int):
+    """Optional: all_gather of the per-rank uint8 masks (equal shard sizes) -> [world*B_local,H,W]."""
+    import torch
+    import torch.distributed as dist
+    out = [torch.empty_like(local_mask) for _ in range(world)]
+    dist.all_gather(out, local_mask)
+    return torch.cat(out, 0)
