@@ -1,6 +1,6 @@
 // aux_kernels.h — the non-GEMM kernels of the UNet++ hot path (all HBM-bound, 16-byte lanes):
 //   weight repack (canonical fp32 OIHW -> per-tile fp16 hi/lo slabs), input conversion,
-//   bilinear-2x upsample + channel concat, 1x1 head + argmax + class masks, debug unpack.
+//   bilinear-2x upsample (the concat is virtual), 1x1 head + argmax + class masks, debug unpack.
 #pragma once
 #include "conv3x3_mfma.h"
 
@@ -98,13 +98,14 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
 }
 
 // ------------------------------------------------------------------------------------------------
-// torch.cat([skip, up(low)], dim=1) with up = nn.Upsample(scale_factor=2, 'bilinear', align_corners=True)
-// (reference unetpp.py:76,111-116).  src = dst*(in-1)/(out-1) in fp32, i0 = int(src),
-// i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1; x is interpolated inside each row first.
+// up = nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (reference unetpp.py:76,112-116).
+// src = dst*(in-1)/(out-1) in fp32, i0 = int(src), i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
+// x is interpolated inside each row first.  The torch.cat([skip, up]) that follows is virtual: the
+// decoder conv reads `skip` and this kernel's output as two sources (conv3x3_mfma.h).
 template <int P>
-__global__ void upsample_concat_kernel(const half_t* __restrict__ skip, int Cs, const half_t* __restrict__ low,
-                                       int Cu, int N, int H, int W, half_t* __restrict__ out) {
-  const int Ct = Cs + Cu, CUN = Ct / 8;
+__global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
+                                  half_t* __restrict__ out) {
+  const int CUN = Cu / 8;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * H * W * CUN;
   if (i >= total) return;
@@ -112,14 +113,8 @@ __global__ void upsample_concat_kernel(const half_t* __restrict__ skip, int Cs, 
   size_t p = i / CUN;
   int x = p % W; size_t q = p / W;
   int y = q % H; int n = q / H;
-  half_t* dst = out + p * P * Ct + cu * 8;
-  if (cu * 8 < Cs) {
-    const half_t* s = skip + p * P * Cs + cu * 8;
-    *(u32x4*)dst = *(const u32x4*)s;
-    if (P == 2) *(u32x4*)(dst + Ct) = *(const u32x4*)(s + Cs);
-    return;
-  }
-  const int c = cu * 8 - Cs;
+  half_t* dst = out + p * P * Cu + cu * 8;
+  const int c = cu * 8;
   const int h = H >> 1, w = W >> 1;
   const float sh = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
@@ -148,7 +143,7 @@ __global__ void upsample_concat_kernel(const half_t* __restrict__ skip, int Cs, 
       rh[e] = hi; rl[e] = lo;
     }
     *(half8*)dst = rh;
-    *(half8*)(dst + Ct) = rl;
+    *(half8*)(dst + Cu) = rl;
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

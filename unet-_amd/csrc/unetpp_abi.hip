@@ -37,13 +37,12 @@ struct Tensor {
 struct ConvLayer {
   std::string name;
   int cin_real = 0;   // channels the canonical weight has
-  int cin_t = 0;      // channels of the input tensor (multiple of 8)
   int cout = 0;
   int lvl = 0;
-  Tensor in, out, pool;
+  Tensor in, in2, out, pool;   // in2: second source of the virtual concat (C = 0 when unused)
   bool do_pool = false;
   size_t w_off = 0, b_off = 0;  // float offsets inside the canonical blob payload
-  int KC = 16, NW = 1, MW = 2;
+  int KC = 16, NW = 1, MW = 2, WAVES = 8;
   int nchunks = 1;
   half_t* wpk = nullptr;
   float* scale = nullptr;
@@ -69,7 +68,7 @@ struct unetpp_engine {
   size_t blob_floats = 0;
   bool weights_loaded = false;
   std::vector<ConvLayer> convs;  // 18
-  Tensor in8, cat[4];            // cat[l] at level l (0..3)
+  Tensor in8, up[4];             // up[l]: bilinear x2 of the level l+1 node, at level l
   Tensor x[5], xa[5], pooled[4], d[4], da[4];  // encoder x{l}_0, its conv1 temp, pooled; decoder nodes
   size_t head_w_off = 0, head_b_off = 0;
   // profiling
@@ -110,48 +109,49 @@ size_t blob_payload_floats(int C, int cin) {
 }
 
 // ---- conv dispatch ---------------------------------------------------------------------------
-template <int P, int KC, int NW, int MW>
+template <int P, int KC, int NW, int MW, int WAVES>
 hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, hipStream_t s) {
-  using C = ConvCfg<P, KC, NW, MW>;
+  using C = ConvCfg<P, KC, NW, MW, WAVES>;
   dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y * a.nct));
   if (pool) {
-    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, true>;
+    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, true>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, s, a);
   } else {
-    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, false>;
+    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, false>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, s, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, hipStream_t s) {
-#define CASE(p, kc, nw, mw) \
-  if (P == p && L.KC == kc && L.NW == nw && L.MW == mw) return launch_conv_cfg<p, kc, nw, mw>(a, L.do_pool, s);
-  CASE(1, 16, 1, 2)
-  CASE(1, 32, 1, 2)
-  CASE(1, 32, 2, 2)
-  CASE(1, 16, 4, 2)
-  CASE(2, 16, 1, 2)
-  CASE(2, 16, 2, 2)
+#define CASE(p, kc, nw, mw, wv) \
+  if (P == p && L.KC == kc && L.NW == nw && L.MW == mw && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw, wv>(a, L.do_pool, s);
+  CASE(1, 16, 1, 2, 8)
+  CASE(1, 32, 1, 2, 4)
+  CASE(1, 32, 2, 2, 8)
+  CASE(1, 16, 4, 2, 8)
+  CASE(2, 16, 1, 2, 8)
+  CASE(2, 16, 2, 2, 8)
 #undef CASE
   return hipErrorInvalidValue;
 }
 
 void choose_cfg(int P, ConvLayer& L) {
-  L.MW = 2;
+  L.MW = 2; L.WAVES = 8;
+  const int cin = L.in.C + L.in2.C;
   if (P == 1) {
-    if (L.cout == 32) { L.NW = 1; L.KC = (L.cin_t <= 16) ? 16 : 32; }
+    if (L.cout == 32) { L.NW = 1; L.KC = (cin <= 16) ? 16 : 32; if (L.KC == 32) L.WAVES = 4; }
     else if (L.cout == 64) { L.NW = 2; L.KC = 32; }
     else { L.NW = 4; L.KC = 16; }
   } else {
     L.KC = 16;
     L.NW = (L.cout == 32) ? 1 : 2;
   }
-  L.nchunks = (L.cin_t + L.KC - 1) / L.KC;
+  L.nchunks = (L.in.C + L.KC - 1) / L.KC + L.in2.C / L.KC;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -232,31 +232,31 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   plan(e->in8, 8, 0);
   for (int l = 0; l < 5; ++l) { plan(e->xa[l], NB[l], l); plan(e->x[l], NB[l], l); }
   for (int l = 0; l < 4; ++l) plan(e->pooled[l], NB[l], l + 1);
-  for (int l = 0; l < 4; ++l) { plan(e->cat[l], NB[l] + NB[l + 1], l); plan(e->da[l], NB[l], l); plan(e->d[l], NB[l], l); }
+  for (int l = 0; l < 4; ++l) { plan(e->up[l], NB[l + 1], l); plan(e->da[l], NB[l], l); plan(e->d[l], NB[l], l); }
 
   // ---- conv layers in forward order; canonical blob offsets
   size_t off = 0;
-  auto add = [&](const std::string& name, int cin_real, const Tensor& in, const Tensor& outT, int lvl, bool pool, const Tensor* poolT) {
+  Tensor none;
+  auto add = [&](const std::string& name, int cin_real, const Tensor& in, const Tensor& in2, const Tensor& outT, int lvl, bool pool) {
     ConvLayer L;
-    L.name = name; L.cin_real = cin_real; L.cin_t = in.C; L.cout = outT.C; L.lvl = lvl;
+    L.name = name; L.cin_real = cin_real; L.in = in; L.in2 = in2; L.out = outT; L.cout = outT.C; L.lvl = lvl;
     L.do_pool = pool;
     L.w_off = off; off += (size_t)L.cout * cin_real * 9;
     L.b_off = off; off += L.cout;
     choose_cfg(P, L);
     e->convs.push_back(L);
-    (void)poolT;
   };
   for (int l = 0; l < 5; ++l) {
     char nm[32];
     snprintf(nm, sizeof nm, "conv%d_0", l);
-    add(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->in8 : e->pooled[l - 1], e->xa[l], l, false, nullptr);
-    add(std::string(nm) + ".conv2", NB[l], e->xa[l], e->x[l], l, l < 4, nullptr);
+    add(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->in8 : e->pooled[l - 1], none, e->xa[l], l, false);
+    add(std::string(nm) + ".conv2", NB[l], e->xa[l], none, e->x[l], l, l < 4);
   }
   for (int l = 3; l >= 0; --l) {
     char nm[32];
     snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
-    add(std::string(nm) + ".conv1", NB[l] + NB[l + 1], e->cat[l], e->da[l], l, false, nullptr);
-    add(std::string(nm) + ".conv2", NB[l], e->da[l], e->d[l], l, false, nullptr);
+    add(std::string(nm) + ".conv1", NB[l] + NB[l + 1], l == 3 ? e->x[3] : e->x[l], e->up[l], e->da[l], l, false);
+    add(std::string(nm) + ".conv2", NB[l], e->da[l], none, e->d[l], l, false);
   }
   e->head_w_off = off; off += (size_t)cfg->num_classes * NB[0];
   e->head_b_off = off; off += cfg->num_classes;
@@ -295,7 +295,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
       e->convs[i].in = e->xa[l]; e->convs[i].out = e->x[l]; if (l < 4) e->convs[i].pool = e->pooled[l]; ++i;
     }
     for (int l = 3; l >= 0; --l) {
-      e->convs[i].in = e->cat[l]; e->convs[i].out = e->da[l]; ++i;
+      e->convs[i].in = e->x[l]; e->convs[i].in2 = e->up[l]; e->convs[i].out = e->da[l]; ++i;
       e->convs[i].in = e->da[l]; e->convs[i].out = e->d[l]; ++i;
     }
   }
@@ -400,35 +400,37 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     auto run_conv = [&](ConvLayer& L) {
       ConvArgs a;
       const int H = h >> L.lvl, W = w >> L.lvl;
-      a.in = L.in.p; a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = L.out.p;
+      a.in0 = L.in.p; a.in1 = L.in2.C ? L.in2.p : nullptr; a.C0 = L.in.C; a.C1 = L.in2.C;
+      a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = L.out.p;
       a.pool_out = L.do_pool ? L.pool.p : nullptr;
-      a.N = nb; a.H = H; a.W = W; a.Cin = L.cin_t; a.Cout = L.cout;
-      a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 4 * L.MW - 1) / (4 * L.MW);
+      a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
+      const int TH = L.WAVES * L.MW;
+      a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
       a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
       double px = (double)nb * H * W;
       double flops = 2.0 * px * L.cout * L.cin_real * 9;
-      double bytes = px * P * 2.0 * (L.cin_t + L.cout) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+      double bytes = px * P * 2.0 * (L.in.C + L.in2.C + L.cout) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
       char lbl[96];
-      snprintf(lbl, sizeof lbl, "%s|conv3x3<P%d,KC%d,NW%d,MW%d,pool%d>", L.name.c_str(), P, L.KC, L.NW, L.MW, (int)L.do_pool);
+      snprintf(lbl, sizeof lbl, "%s|conv3x3<P%d,KC%d,NW%d,MW%d,W%d,pool%d>", L.name.c_str(), P, L.KC, L.NW, L.MW, L.WAVES, (int)L.do_pool);
       Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, s); });
     };
-    auto run_upcat = [&](int l, const Tensor& skip, const Tensor& low) {
+    auto run_up = [&](int l, const Tensor& low) {
       const int H = h >> l, W = w >> l;
-      size_t total = (size_t)nb * H * W * ((skip.C + low.C) / 8);
+      size_t total = (size_t)nb * H * W * (low.C / 8);
       double px = (double)nb * H * W;
-      double bytes = px * P * 2.0 * (skip.C + (skip.C + low.C)) + px / 4 * P * 2.0 * low.C;
+      double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
       char nm[64];
-      snprintf(nm, sizeof nm, "upcat%d|upsample_concat<P%d>", l, P);
+      snprintf(nm, sizeof nm, "up%d|upsample2x<P%d>", l, P);
       Lx.run(nm, px * low.C * 8, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(upsample_concat_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, skip.p, skip.C, low.p, low.C, nb, H, W, e->cat[l].p);
-        else hipLaunchKernelGGL(upsample_concat_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, skip.p, skip.C, low.p, low.C, nb, H, W, e->cat[l].p);
+        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
+        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
         return hipSuccess;
       });
     };
     size_t li = 0;
     for (int l = 0; l < 5; ++l) { run_conv(e->convs[li]); ++li; run_conv(e->convs[li]); ++li; }
     for (int l = 3; l >= 0; --l) {
-      run_upcat(l, e->x[l], l == 3 ? e->x[4] : e->d[l + 1]);
+      run_up(l, l == 3 ? e->x[4] : e->d[l + 1]);
       run_conv(e->convs[li]); ++li;
       run_conv(e->convs[li]); ++li;
     }
