@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "../unet-_amd/csrc/conv3x3_mfma.h"
 using namespace unetpp;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -16,7 +17,9 @@ float run(ConvArgs a, int reps) {
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
   a.tiles_x = (a.W + 31) / 32; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
   a.nchunks = (a.C0 + KC - 1) / KC + a.C1 / KC;
-  dim3 grid(a.N * a.tiles_x * a.tiles_y * a.nct);
+  int total = a.N * a.tiles_x * a.tiles_y * a.nct;
+  int per_cu = std::max(1, std::min(2, (160 * 1024) / C::LDS_BYTES));
+  dim3 grid(std::min(total, 256 * per_cu));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, 0, a);
   CK(hipDeviceSynchronize());
@@ -28,7 +31,7 @@ float run(ConvArgs a, int reps) {
 #ifdef UNETPP_STAMP
   unsigned long long hs[32];
   CK(hipMemcpy(hs, a.pool_out, sizeof hs, hipMemcpyDeviceToHost));
-  for (int w = 0; w < 8; ++w) printf("wave %d per-chunk cycles: issue %llu mfma %llu commit+vmwait %llu barrier %llu\n", w, hs[w*4]/a.nchunks, hs[w*4+1]/a.nchunks, hs[w*4+2]/a.nchunks, hs[w*4+3]/a.nchunks);
+  for (int w = 0; w < 8; ++w) printf("wave %d cycles: prologue %llu | per-chunk mfma %llu barrier %llu (x%d chunks) | epilogue %llu\n", w, hs[w*4], hs[w*4+1]/a.nchunks, hs[w*4+2]/a.nchunks, a.nchunks, hs[w*4+3]);
 #endif
   return ms / reps;
 }

@@ -23,9 +23,9 @@
 //          ds_write_b128 (2 pixels x 4 channel groups) hit distinct banks; the A-fragment ds_read_b128 of
 //          a 32x16 tile reads 2 x 512 contiguous bytes -> conflict-free.
 //   slab   [P][tap][KG][BN][8 halves]           B-fragment read = 2 x 512 contiguous bytes.
-//   The epilogue tile [pixel][P][EPN] fp16 reuses the staging memory after the last chunk: global stores
-//   are full 16-byte lanes on contiguous channel runs and the 2x2 max-pool (unetpp.py:75) is taken
-//   from it without another pass over HBM.
+// Workgroups are persistent: each walks tiles blockIdx.x, +gridDim.x, ... and prefetches the first chunk
+// of its next tile during the last chunk of the current one, so only the first tile pays the cold
+// HBM burst.  The epilogue runs from registers (see run_mfma / pack_store): no LDS, no barrier.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,6 +34,7 @@ namespace unetpp {
 
 typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 typedef __attribute__((ext_vector_type(16))) float float16v;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -67,10 +68,7 @@ struct ConvCfg {
   static constexpr int HALO_BYTES = P * KG * KGS;
   static constexpr int SLAB_BYTES = P * 9 * KC * BN * 2;
   static constexpr int BUF_BYTES = HALO_BYTES + SLAB_BYTES;
-  static constexpr int EPN = BN < 64 ? BN : 64;
-  static constexpr int EP_BYTES = TH * TW * P * EPN * 2;
-  static constexpr int STAGE_BYTES = 2 * BUF_BYTES;
-  static constexpr int LDS_BYTES = STAGE_BYTES > EP_BYTES ? STAGE_BYTES : EP_BYTES;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
   static constexpr int HALO_ITEMS = NHALO * P * KG;
   static constexpr int HALO_ITERS = (HALO_ITEMS + NT - 1) / NT;
   static constexpr int SLAB_PIECES = SLAB_BYTES / 1024;   // one LDS-DMA wave-instruction = 1 KiB
@@ -103,38 +101,23 @@ template <int P, int KC, int NW, int MW, int WAVES, bool POOL>
 __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs a) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
-  constexpr int KG = C::KG, BN = C::BN, KGS = C::KGS, EPN = C::EPN;
+  constexpr int KG = C::KG, BN = C::BN, KGS = C::KGS;
   constexpr int ITERS = C::HALO_ITERS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  int bid = blockIdx.x;
-  const int ct = bid % a.nct;
-  int pt = bid / a.nct;
-  const int tx = pt % a.tiles_x; pt /= a.tiles_x;
-  const int ty = pt % a.tiles_y;
-  const int n = pt / a.tiles_y;
-  const int x0 = tx * TW, y0 = ty * TH;
   const int H = a.H, W = a.W;
+  const int tiles_img = a.tiles_x * a.tiles_y;
+  const int total_tiles = a.N * tiles_img * a.nct;
+  const int nch0 = (a.C0 + KC - 1) / KC;
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
 
-  float16v acc[MW][NW];
-#pragma unroll
-  for (int m = 0; m < MW; ++m)
-#pragma unroll
-    for (int j = 0; j < NW; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
-
-  // ---- chunk-invariant halo item geometry (per thread: ITERS items of 16 bytes).  The loads are raw
-  // buffer loads: one descriptor per source covering image n, per-lane byte offset precomputed here,
-  // the chunk's channel offset in the scalar soffset; pixels outside the image (zero padding) and
-  // unused items carry an out-of-range offset and read back zeros — no branches in the K loop.
-  constexpr unsigned OOB = 0x80000000u;
-  unsigned voff0[ITERS], voff1[ITERS];
-  int ldsoff[ITERS];   // byte offset inside the halo image, -1 = unused item
+  // ---- tile-invariant halo item geometry (per thread: ITERS items of 16 bytes)
+  int hyx[ITERS];      // (hy << 8) | hx of the halo pixel, -1 = unused item
+  int plkg[ITERS];     // (pl << 8) | kg*8
+  int ldsoff[ITERS];   // byte offset inside the halo image
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int i = tid + it * NT;
@@ -142,21 +125,47 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     const int pl = (i / KG) % P;
     const int hp = i / (KG * P);
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-    const bool ok = (i < C::HALO_ITEMS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const unsigned pix = (unsigned)((gy * W + gx) * P + pl);
-    voff0[it] = (ok && kg * 8 < a.C0) ? (pix * a.C0 + kg * 8) * 2u : OOB;
-    voff1[it] = ok ? (pix * a.C1 + kg * 8) * 2u : OOB;
-    ldsoff[it] = (i < C::HALO_ITEMS) ? (pl * KG + kg) * KGS + hp * 16 : -1;
+    hyx[it] = (i < C::HALO_ITEMS) ? ((hy << 8) | hx) : -1;
+    plkg[it] = (pl << 8) | (kg * 8);
+    ldsoff[it] = (pl * KG + kg) * KGS + hp * 16;
   }
-  const size_t img = (size_t)n * H * W * P;
+
+  // ---- per-tile state: the tile being computed (cur_*) and the source state of the tile whose
+  // chunks are being loaded (voff*, rsrc*, wsrc) — the latter switches to the next tile one chunk early.
+  constexpr unsigned OOB = 0x80000000u;   // beyond num_records: the buffer load returns zeros
+  unsigned voff0[ITERS], voff1[ITERS];
+  __amdgpu_buffer_rsrc_t rsrc0, rsrc1;
+  const char* wsrc;
   const unsigned img_bytes0 = (unsigned)(H * W * P * a.C0 * 2), img_bytes1 = (unsigned)(H * W * P * a.C1 * 2);
-  const __amdgpu_buffer_rsrc_t rsrc0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + img * a.C0), 0, (int)img_bytes0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.in1 ? a.in1 + img * a.C1 : a.in0), 0, (int)(a.in1 ? img_bytes1 : 0u), 0x00020000);
-  const int nch0 = (a.C0 + KC - 1) / KC;
-  const char* wsrc = (const char*)a.wpk + (size_t)ct * a.nchunks * C::SLAB_BYTES;
+  int cur_n, cur_y0, cur_x0, cur_ct;
+  auto decode = [&](int t, int& n, int& y0, int& x0, int& ct) {
+    ct = t % a.nct;
+    int pt = t / a.nct;
+    const int tx = pt % a.tiles_x; pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    n = pt / a.tiles_y;
+    x0 = tx * TW; y0 = ty * TH;
+  };
+  // Raw buffer loads: one descriptor per source covering image n, per-lane byte offset computed once per
+  // tile, the chunk's channel offset in the scalar soffset; pixels outside the image (zero padding) and
+  // unused items carry an out-of-range offset and read back zeros — no branches in the K loop.
+  auto setup_sources = [&](int n, int y0, int x0, int ct) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const int pl = plkg[it] >> 8, k8 = plkg[it] & 255;
+      const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const unsigned pix = (unsigned)((gy * W + gx) * P + pl);
+      voff0[it] = (ok && k8 < a.C0) ? (pix * a.C0 + k8) * 2u : OOB;
+      voff1[it] = ok ? (pix * a.C1 + k8) * 2u : OOB;
+    }
+    const size_t img = (size_t)n * H * W * P;
+    rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + img * a.C0), 0, (int)img_bytes0, 0x00020000);
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 ? a.in1 + img * a.C1 : a.in0), 0,
+                                              (int)(a.in1 ? img_bytes1 : 0u), 0x00020000);
+    wsrc = (const char*)a.wpk + (size_t)ct * a.nchunks * C::SLAB_BYTES;
+  };
 
   u32x4 hv[ITERS];
   auto halo_issue_one = [&](int c, int it) {     // `it` is a compile-time constant at every call site
@@ -166,9 +175,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   auto halo_commit = [&](char* halo) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it)
-      if (ldsoff[it] >= 0) *(u32x4*)(halo + ldsoff[it]) = hv[it];
+      if (hyx[it] >= 0) *(u32x4*)(halo + ldsoff[it]) = hv[it];
   };
-  const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
   constexpr int DMA_PER_WAVE = (C::SLAB_PIECES + WAVES - 1) / WAVES;
   auto slab_dma_one = [&](int c, int slab_off, int p) {
     const int piece = wave + p * WAVES;
@@ -197,27 +205,30 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       if (P == 2) f.bl[j] = *(const half8*)(slab + off + 9 * KC * BN * 2);
     }
   };
+  float16v acc[MW][NW];
+  // D = W^T-tile x pixel-tile: the weights go in as the MFMA's A operand and the pixels as B, so the
+  // accumulator has the PIXEL on the lane (col = lane & 31) and 16 output channels in its registers
+  // (channel = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): four consecutive channels sit in four
+  // consecutive registers, which is what lets the epilogue pack and store 16-byte channel runs (and
+  // take the 2x2 max-pool) straight from registers.
   auto run_mfma = [&](const Frag& f) {
-#ifdef UNETPP_ABLATE_MFMA   // dev-only timing build: keep the fragments live, issue no MFMA
-#pragma unroll
-    for (int m = 0; m < MW; ++m) { asm volatile("" ::"v"(f.ah[m])); if (P == 2) asm volatile("" ::"v"(f.al[m])); }
-#pragma unroll
-    for (int j = 0; j < NW; ++j) { asm volatile("" ::"v"(f.bh[j])); if (P == 2) asm volatile("" ::"v"(f.bl[j])); }
-    return;
-#endif
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         if (P == 2) {
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[j], acc[m][j], 0, 0, 0);
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl[j], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[m], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[m], acc[m][j], 0, 0, 0);
         }
-        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh[j], acc[m][j], 0, 0, 0);
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[m], acc[m][j], 0, 0, 0);
       }
   };
 
-  // ---- prologue: chunk 0 -> buffer 0
+  // ---- first tile: chunk 0 -> buffer 0
+  int tile = blockIdx.x;
+  if (tile >= total_tiles) return;
+  decode(tile, cur_n, cur_y0, cur_x0, cur_ct);
+  setup_sources(cur_n, cur_y0, cur_x0, cur_ct);
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) halo_issue_one(0, it);
 #pragma unroll
@@ -226,160 +237,147 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#ifdef UNETPP_STAMP
-  unsigned long long st_issue = 0, st_mfma = 0, st_commit = 0, st_barrier = 0, st_t;
-#define STAMP(acc_) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); acc_ += t_ - st_t; st_t = t_; } while (0)
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory");
-#else
-#define STAMP(acc_)
-#endif
-  for (int c = 0; c < a.nchunks; ++c) {
-    char* cur = smem + (c & 1) * C::BUF_BYTES;
-    char* nxt = smem + ((c & 1) ^ 1) * C::BUF_BYTES;
-#ifdef UNETPP_ABLATE_GLOBAL   // dev-only timing build: no global traffic after the prologue
-    const bool more = false;
-#else
-    const bool more = c + 1 < a.nchunks;
-#endif
-    const int nxt_slab = ((c & 1) ^ 1) * C::BUF_BYTES + C::HALO_BYTES;
-    // ---- MFMA over 9 taps x KC from the current buffer.  One step = one tap x 16 channels; the
-    // fragments of step t+1 are read from LDS (into the other register set) before the MFMAs of
-    // step t issue, so the LDS latency hides under the matrix pipe.  The next chunk's global loads
-    // (one halo item + one DMA piece per step) are spread over the first steps instead of being
-    // issued in one burst, and the halo registers are committed to the other buffer just before the
-    // last step's MFMAs, so neither the vector-memory issue queue nor the LDS writes idle the pipe.
-    const char* halo = cur;
-    const char* slab = cur + C::HALO_BYTES;
-    constexpr int NSTEPS = 9 * (KC / 16);
-    constexpr int HPS = (ITERS + NSTEPS - 2) / (NSTEPS - 1);          // halo items issued per step
-    constexpr int DPS = (DMA_PER_WAVE + NSTEPS - 2) / (NSTEPS - 1);   // DMA pieces issued per step
-    Frag f0, f1;
-    load_frags(f0, halo, slab, 0);
+  int g = 0;   // global chunk counter: chunk g lives in stage buffer g & 1
+  for (;;) {
 #pragma unroll
-    for (int st = 0; st < NSTEPS; ++st) {
-      Frag& fc = (st & 1) ? f1 : f0;
-      Frag& fn = (st & 1) ? f0 : f1;
-      if (st + 1 < NSTEPS) load_frags(fn, halo, slab, st + 1);
-      if (more) {
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int k = st * HPS; k < (st + 1) * HPS; ++k)
-          if (k < ITERS) halo_issue_one(c + 1, k);
+      for (int j = 0; j < NW; ++j)
 #pragma unroll
-        for (int k = st * DPS; k < (st + 1) * DPS; ++k)
-          if (k < DMA_PER_WAVE) slab_dma_one(c + 1, nxt_slab, k);
-        if (st == NSTEPS - 1) halo_commit(nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);      // keep prefetch + load issue ahead of this step's MFMAs
-      run_mfma(fc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    STAMP(st_mfma);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-    STAMP(st_commit);
-    __syncthreads();
-    STAMP(st_barrier);
-  }
+        for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
-#ifdef UNETPP_STAMP
-  if (blockIdx.x == 7 && lane == 0) {
-    unsigned long long* dbg = (unsigned long long*)a.pool_out + wave * 4;
-    dbg[0] = st_issue; dbg[1] = st_mfma; dbg[2] = st_commit; dbg[3] = st_barrier;
-  }
-#endif
-  // ---- epilogue: scale, bias, ReLU -> LDS tile -> coalesced stores (+ fused 2x2 max-pool)
-  half_t* ep = (half_t*)smem;
-  const int Cout = a.Cout;
+    const int next_tile = tile + (int)gridDim.x;
+    const bool have_next = next_tile < total_tiles;
+    for (int c = 0; c < a.nchunks; ++c, ++g) {
+      char* cur = smem + (g & 1) * C::BUF_BYTES;
+      char* nxt = smem + ((g & 1) ^ 1) * C::BUF_BYTES;
+      const int nxt_slab = ((g & 1) ^ 1) * C::BUF_BYTES + C::HALO_BYTES;
+      const bool last = c + 1 == a.nchunks;
+      const bool more = !last || have_next;
+      const int pc = last ? 0 : c + 1;          // chunk to prefetch (of this tile, or chunk 0 of the next)
+      if (last && have_next) {                   // every load of this tile has been issued: switch sources
+        int n2, y2, x2, ct2;
+        decode(next_tile, n2, y2, x2, ct2);
+        setup_sources(n2, y2, x2, ct2);
+      }
+      // ---- MFMA over 9 taps x KC from the current buffer.  One step = one tap x 16 channels; the
+      // fragments of step t+1 are read from LDS (into the other register set) before the MFMAs of
+      // step t issue, so the LDS latency hides under the matrix pipe.  The next chunk's global loads
+      // (halo items + DMA pieces) are spread over the steps instead of being issued in one burst, and
+      // the halo registers are committed to the other buffer just before the last step's MFMAs, so
+      // neither the vector-memory issue queue nor the LDS writes idle the pipe.
+      const char* halo = cur;
+      const char* slab = cur + C::HALO_BYTES;
+      constexpr int NSTEPS = 9 * (KC / 16);
+      constexpr int HPS = (ITERS + NSTEPS - 2) / (NSTEPS - 1);          // halo items issued per step
+      constexpr int DPS = (DMA_PER_WAVE + NSTEPS - 2) / (NSTEPS - 1);   // DMA pieces issued per step
+      Frag f0, f1;
+      load_frags(f0, halo, slab, 0);
 #pragma unroll
-  for (int j0 = 0; j0 < NW; j0 += EPN / 32) {
-    if (j0) __syncthreads();
+      for (int st = 0; st < NSTEPS; ++st) {
+        Frag& fc = (st & 1) ? f1 : f0;
+        Frag& fn = (st & 1) ? f0 : f1;
+        if (st + 1 < NSTEPS) load_frags(fn, halo, slab, st + 1);
+        if (more) {
 #pragma unroll
-    for (int jj = 0; jj < EPN / 32; ++jj) {
-      const int j = j0 + jj;
-      const int co = ct * BN + j * 32 + (lane & 31);
-      const float sc = a.scale[co], bi = a.bias[co];
+          for (int k = st * HPS; k < (st + 1) * HPS; ++k)
+            if (k < ITERS) halo_issue_one(pc, k);
 #pragma unroll
-      for (int m = 0; m < MW; ++m) {
-        const int row = wave * MW + m;
+          for (int k = st * DPS; k < (st + 1) * DPS; ++k)
+            if (k < DMA_PER_WAVE) slab_dma_one(pc, nxt_slab, k);
+          if (st == NSTEPS - 1) halo_commit(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep prefetch + load issue ahead of this step's MFMAs
+        run_mfma(fc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+      __syncthreads();
+    }
+
+    // ---- epilogue straight from registers: scale, bias, ReLU, fp16 (hi/lo) packing, one
+    // v_permlane32_swap per word so that every lane owns 8 consecutive channels, 16-byte stores;
+    // the fused 2x2 max-pool (unetpp.py:75) is max(row m=0, row m=1) in-lane and one DPP exchange
+    // between neighbouring pixel lanes.  No LDS, no barrier: the stores drain under the next tile's MFMAs.
+    {
+      const int Cout = a.Cout;
+      const int h = lane >> 5;
+      const int gx = cur_x0 + (lane & 31);
+      const size_t img_px = (size_t)cur_n * H * W;
+      auto pack_store = [&](const float (&v)[16], half_t* dst /* -> channel j*32 of the pixel, plane 0 */, bool ok) {
+        unsigned wh[4][2], wl[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            const float v0 = fminf(v[4 * q + 2 * w2], 65504.0f), v1 = fminf(v[4 * q + 2 * w2 + 1], 65504.0f);
+            const half_t h0 = (half_t)v0, h1 = (half_t)v1;
+            half2v ph = {h0, h1};
+            wh[q][w2] = __builtin_bit_cast(unsigned, ph);
+            if (P == 2) {
+              half2v pl = {(half_t)(v0 - (float)h0), (half_t)(v1 - (float)h1)};
+              wl[q][w2] = __builtin_bit_cast(unsigned, pl);
+            }
+          }
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            auto r = __builtin_amdgcn_permlane32_swap(wh[2 * pi][w2], wh[2 * pi + 1][w2], false, false);
+            wh[2 * pi][w2] = r[0]; wh[2 * pi + 1][w2] = r[1];
+            if (P == 2) {
+              auto r2 = __builtin_amdgcn_permlane32_swap(wl[2 * pi][w2], wl[2 * pi + 1][w2], false, false);
+              wl[2 * pi][w2] = r2[0]; wl[2 * pi + 1][w2] = r2[1];
+            }
+          }
+          if (ok) {
+            u32x4 o = {wh[2 * pi][0], wh[2 * pi][1], wh[2 * pi + 1][0], wh[2 * pi + 1][1]};
+            *(u32x4*)(dst + 16 * pi + 8 * h) = o;
+            if (P == 2) {
+              u32x4 o2 = {wl[2 * pi][0], wl[2 * pi][1], wl[2 * pi + 1][0], wl[2 * pi + 1][1]};
+              *(u32x4*)(dst + Cout + 16 * pi + 8 * h) = o2;
+            }
+          }
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int cbase = cur_ct * BN + j * 32;
+        float v[MW][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int x = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          float v = fmaxf(acc[m][j][r] * sc + bi, 0.f);
-          const int idx = ((row * TW + x) * P) * EPN + jj * 32 + (lane & 31);
-          if (P == 2) {
-            half_t hi, lo;
-            split_f16(v, hi, lo);
-            ep[idx] = hi;
-            ep[idx + EPN] = lo;
-          } else {
-            ep[idx] = (half_t)fminf(v, 65504.0f);
+          const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float sc = a.scale[co], bi = a.bias[co];
+#pragma unroll
+          for (int m = 0; m < MW; ++m) v[m][r] = fmaxf(acc[m][j][r] * sc + bi, 0.f);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+          const int gy = cur_y0 + wave * MW + m;
+          const bool ok = gy < H && gx < W;
+          half_t* dst = a.out + ((img_px + (size_t)gy * W + gx) * P) * Cout + cbase;
+          pack_store(v[m], dst, ok);
+        }
+        if (POOL) {
+          static_assert(!POOL || MW == 2, "fused pool needs both rows of a 2x2 window in one wave");
+          float pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float vm = fmaxf(v[0][r], v[MW - 1][r]);
+            const float vn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vm), 0xB1, 0xF, 0xF, true));
+            pv[r] = fmaxf(vm, vn);       // quad_perm [1,0,3,2]: the horizontally adjacent pixel
           }
+          const int Hp = H >> 1, Wp = W >> 1;
+          const int py = (cur_y0 >> 1) + wave, px = (cur_x0 >> 1) + ((lane & 31) >> 1);
+          const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
+          half_t* dst = a.pool_out + (((size_t)cur_n * Hp * Wp + (size_t)py * Wp + px) * P) * Cout + cbase;
+          pack_store(pv, dst, ok);
         }
       }
     }
-    __syncthreads();
-    {
-      constexpr int CU = EPN / 8;
-      constexpr int UNITS = TH * TW * P * CU;
-      static_assert(UNITS % NT == 0, "epilogue units");
-      half_t* out_n = a.out + (size_t)n * H * W * P * Cout;
-#pragma unroll
-      for (int it = 0; it < UNITS / NT; ++it) {
-        int u = tid + it * NT;
-        int cu = u % CU;
-        int pl = (u / CU) % P;
-        int px = u / (CU * P);
-        int gy = y0 + px / TW, gx = x0 + px % TW;
-        if (gy < H && gx < W)
-          *(u32x4*)(out_n + ((size_t)(gy * W + gx) * P + pl) * Cout + ct * BN + j0 * 32 + cu * 8) =
-              *(const u32x4*)(ep + (size_t)u * 8);
-      }
-    }
-    if (POOL) {
-      constexpr int CU = EPN / 8;
-      constexpr int PUNITS = (TH / 2) * (TW / 2) * CU;
-      const int Hp = H >> 1, Wp = W >> 1;
-      half_t* pool_n = a.pool_out + (size_t)n * Hp * Wp * P * Cout;
-      for (int u = tid; u < PUNITS; u += NT) {
-        int cu = u % CU;
-        int pp = u / CU;
-        int py = pp / (TW / 2), px = pp % (TW / 2);
-        int gy = (y0 >> 1) + py, gx = (x0 >> 1) + px;
-        if (gy >= Hp || gx >= Wp) continue;
-        const half_t* p00 = ep + ((size_t)((2 * py) * TW + 2 * px) * P) * EPN + cu * 8;
-        const int dxs = P * EPN, dys = TW * P * EPN;
-        half_t* dst = pool_n + ((size_t)(gy * Wp + gx) * P) * Cout + ct * BN + j0 * 32 + cu * 8;
-        if (P == 1) {
-          half8 q0 = *(const half8*)p00, q1 = *(const half8*)(p00 + dxs);
-          half8 q2 = *(const half8*)(p00 + dys), q3 = *(const half8*)(p00 + dys + dxs);
-          half8 r;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            half_t m0 = q0[e] > q1[e] ? q0[e] : q1[e];
-            half_t m1 = q2[e] > q3[e] ? q2[e] : q3[e];
-            r[e] = m0 > m1 ? m0 : m1;
-          }
-          *(half8*)dst = r;
-        } else {
-          half8 rh, rl;
-          half8 h0 = *(const half8*)p00, l0 = *(const half8*)(p00 + EPN);
-          half8 h1 = *(const half8*)(p00 + dxs), l1 = *(const half8*)(p00 + dxs + EPN);
-          half8 h2 = *(const half8*)(p00 + dys), l2 = *(const half8*)(p00 + dys + EPN);
-          half8 h3 = *(const half8*)(p00 + dys + dxs), l3 = *(const half8*)(p00 + dys + dxs + EPN);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v0 = (float)h0[e] + (float)l0[e], v1 = (float)h1[e] + (float)l1[e];
-            float v2 = (float)h2[e] + (float)l2[e], v3 = (float)h3[e] + (float)l3[e];
-            float v = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-            half_t hi, lo;
-            split_f16(v, hi, lo);
-            rh[e] = hi;
-            rl[e] = lo;
-          }
-          *(half8*)dst = rh;
-          *(half8*)(dst + Cout) = rl;
-        }
-      }
-    }
+    if (!have_next) break;
+    tile = next_tile;
+    decode(tile, cur_n, cur_y0, cur_x0, cur_ct);
   }
 }
 

@@ -7,6 +7,7 @@
 //   out  = Conv1x1(32,C)(x0_4)  -> argmax / class masks (infer_two_stage_burr.py:299-304)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -109,10 +110,15 @@ size_t blob_payload_floats(int C, int cin) {
 }
 
 // ---- conv dispatch ---------------------------------------------------------------------------
+int g_num_cus = 256;
+
 template <int P, int KC, int NW, int MW, int WAVES>
 hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
-  dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y * a.nct));
+  // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
+  const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
+  const int per_cu = std::max(1, std::min(2, (160 * 1024) / C::LDS_BYTES));
+  dim3 grid((unsigned)std::min(total, g_num_cus * per_cu));
   if (pool) {
     auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, true>;
     static bool attr = false;
@@ -212,6 +218,10 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     return fail(nullptr, UNETPP_E_HIP, "no HIP device available: this engine has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, UNETPP_E_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
   HIP_TRY(nullptr, hipSetDevice(cfg->device));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
+  }
 
   unetpp_engine* e = new unetpp_engine();
   e->cfg = *cfg;
