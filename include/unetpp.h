@@ -117,6 +117,11 @@ int unetpp_profile_work(const unetpp_engine* e, int i, double* flops, double* by
  * host memory as float32 [b,C,h,w]; returns the number of floats written or a negative error. */
 long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out, size_t max_floats);
 
+/* x0_4 is normally never written to HBM (the 1x1 head + argmax run in the epilogue of conv0_4.conv2).
+ * With on != 0 the next forwards materialise it and run the head as a separate kernel, so that
+ * unetpp_debug_read("x0_4") works. */
+int unetpp_debug_keep_intermediates(unetpp_engine* e, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,10 @@ def test_exact_matches_golden_small(tag, torch_cuda, syn, oracle):
     err, flips, unexplained = report(logits.cpu().numpy(), mask.cpu().numpy(), g["logits"], g["mask"], oracle)
     print(f"{tag}: max|dlogit|={err:.3e} flips={flips}")
     if tag == "s_c3_32x32":                 # layer-by-layer against the reference's intermediates
+        model.debug_keep_intermediates(True)          # unfused head path: materialises x0_4
+        logits_unfused = model(x)
+        torch.cuda.synchronize()
+        assert float((logits_unfused - logits).abs().max()) < 2e-6     # fused and unfused heads agree
         for name in NODES:
             got = model.debug_activation(name, B, H, W)
             np.testing.assert_allclose(got, g["t_" + name], rtol=0, atol=2e-5, err_msg=name)

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
     "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_workspace_bytes",
     "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
-    "unetpp_profile_work", "unetpp_debug_read",
+    "unetpp_profile_work", "unetpp_debug_read", "unetpp_debug_keep_intermediates",
 ]
 
 PREC_EXACT, PREC_FAST = 0, 1
@@ -83,5 +83,6 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_profile_work.restype = ci
     lib.unetpp_debug_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), cs]
     lib.unetpp_debug_read.restype = ctypes.c_longlong
+    lib.unetpp_debug_keep_intermediates.argtypes = [vp, ci]; lib.unetpp_debug_keep_intermediates.restype = ci
     _lib = lib
     return lib

@@ -158,7 +158,6 @@ __global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N,
 // self.final = Conv2d(32, C, 1) (unetpp.py:85,119) in fp32, then the frame-loop tail
 // softmax -> argmax -> uint8, (pred==1), (pred==2) (infer_two_stage_burr.py:299-304).  softmax is
 // monotone, so the class index is taken on the logits; ties resolve to the lowest index (np.argmax).
-constexpr int HEAD_MAX_CLASSES = 16;
 template <int P>
 __global__ void head_argmax_kernel(const half_t* __restrict__ x, const float* __restrict__ w /*[C][32]*/,
                                    const float* __restrict__ b, int C, int N, int H, int W,

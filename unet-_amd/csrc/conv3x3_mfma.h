@@ -50,6 +50,15 @@ struct ConvArgs {
   int tiles_x, tiles_y;  // spatial tiles per image
   int nct;               // Cout / BN
   int nchunks;           // ceil(C0 / KC) + C1 / KC
+  // fused 1x1 head + argmax (HEAD variant, Cout == 32 == BN): self.final (unetpp.py:85,119) and the
+  // frame-loop tail softmax->argmax->uint8, (pred==1), (pred==2) (infer_two_stage_burr.py:299-304)
+  const float* head_w;   // [C][32] fp32
+  const float* head_b;   // [C]
+  int head_C;
+  float* logits;         // [N][C][H][W] fp32 or nullptr
+  uint8_t* mask;         // [N][H][W] or nullptr
+  uint8_t* cable;        // or nullptr
+  uint8_t* tape;         // or nullptr
 };
 
 __host__ __device__ constexpr int conv_kgs(int nhalo) {
@@ -97,7 +106,9 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                : "memory");
 }
 
-template <int P, int KC, int NW, int MW, int WAVES, bool POOL>
+constexpr int HEAD_MAX_CLASSES = 16;
+
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false>
 __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs a) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
@@ -223,6 +234,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[m], acc[m][j], 0, 0, 0);
       }
   };
+
+  float* head_lds = (float*)(smem + C::LDS_BYTES);   // HEAD only: [C][32] weights then [C] biases
+  if (HEAD) {
+    static_assert(!HEAD || (NW == 1 && !POOL), "the fused head needs all 32 channels of x0_4 in one tile");
+    for (int i = tid; i < a.head_C * 32; i += NT) head_lds[i] = a.head_w[i];
+    for (int i = tid; i < a.head_C; i += NT) head_lds[a.head_C * 32 + i] = a.head_b[i];
+  }
 
   // ---- first tile: chunk 0 -> buffer 0
   int tile = blockIdx.x;
@@ -351,12 +369,41 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
 #pragma unroll
           for (int m = 0; m < MW; ++m) v[m][r] = fmaxf(acc[m][j][r] * sc + bi, 0.f);
         }
+        if (!HEAD) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-          const int gy = cur_y0 + wave * MW + m;
-          const bool ok = gy < H && gx < W;
-          half_t* dst = a.out + ((img_px + (size_t)gy * W + gx) * P) * Cout + cbase;
-          pack_store(v[m], dst, ok);
+          for (int m = 0; m < MW; ++m) {
+            const int gy = cur_y0 + wave * MW + m;
+            const bool ok = gy < H && gx < W;
+            half_t* dst = a.out + ((img_px + (size_t)gy * W + gx) * P) * Cout + cbase;
+            pack_store(v[m], dst, ok);
+          }
+        } else {
+          // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: 16 channels in this lane, the other 16
+          // in lane ^ 32 (one cross-half shuffle); first maximal class wins.
+          const size_t hw = (size_t)H * W;
+#pragma unroll
+          for (int m = 0; m < MW; ++m) {
+            const int gy = cur_y0 + wave * MW + m;
+            const bool ok = h == 0 && gy < H && gx < W;
+            const size_t pix = (size_t)gy * W + gx;
+            float best = -INFINITY;
+            int besti = 0;
+            for (int c = 0; c < a.head_C; ++c) {
+              float part = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) part = fmaf(v[m][r], head_lds[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
+              const float other = __shfl_xor(part, 32, 64);
+              const float s = head_lds[a.head_C * 32 + c] + (h == 0 ? part + other : other + part);   // same order in both lanes
+              if (ok && a.logits) a.logits[((size_t)cur_n * a.head_C + c) * hw + pix] = s;
+              if (s > best) { best = s; besti = c; }
+            }
+            if (ok) {
+              const size_t o = (size_t)cur_n * hw + pix;
+              if (a.mask) a.mask[o] = (uint8_t)besti;
+              if (a.cable) a.cable[o] = besti == 1;
+              if (a.tape) a.tape[o] = besti == 2;
+            }
+          }
         }
         if (POOL) {
           static_assert(!POOL || MW == 2, "fused pool needs both rows of a 2x2 window in one wave");

@@ -77,6 +77,7 @@ struct unetpp_engine {
   std::vector<ProfRec> prof;
   int prof_used = 0;
   int last_b = 0, last_h = 0, last_w = 0;
+  bool keep_all = false;   // debug: materialise x0_4 and run the head as its own kernel
 };
 
 namespace {
@@ -112,30 +113,33 @@ size_t blob_payload_floats(int C, int cin) {
 // ---- conv dispatch ---------------------------------------------------------------------------
 int g_num_cus = 256;
 
-template <int P, int KC, int NW, int MW, int WAVES>
-hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, hipStream_t s) {
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
+hipError_t launch_conv_k(const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
+  const int lds = C::LDS_BYTES + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
-  const int per_cu = std::max(1, std::min(2, (160 * 1024) / C::LDS_BYTES));
+  const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
   dim3 grid((unsigned)std::min(total, g_num_cus * per_cu));
-  if (pool) {
-    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, true>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, s, a);
-  } else {
-    auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, false>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, s, a);
-  }
+  auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD>;
+  static int attr_lds = 0;
+  if (attr_lds < lds) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
+  hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, hipStream_t s) {
+template <int P, int KC, int NW, int MW, int WAVES>
+hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, bool head, hipStream_t s) {
+  if constexpr (NW == 1) {
+    if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(a, s);
+  }
+  if (pool) return launch_conv_k<P, KC, NW, MW, WAVES, true, false>(a, s);
+  return launch_conv_k<P, KC, NW, MW, WAVES, false, false>(a, s);
+}
+
+hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, hipStream_t s) {
 #define CASE(p, kc, nw, mw, wv) \
-  if (P == p && L.KC == kc && L.NW == nw && L.MW == mw && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw, wv>(a, L.do_pool, s);
+  if (P == p && L.KC == kc && L.NW == nw && L.MW == mw && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw, wv>(a, L.do_pool, head, s);
   CASE(1, 16, 1, 2, 8)
   CASE(1, 32, 1, 2, 4)
   CASE(1, 32, 2, 2, 8)
@@ -407,8 +411,12 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
         return hipSuccess;
       });
     }
-    auto run_conv = [&](ConvLayer& L) {
-      ConvArgs a;
+    float* lg = dev_logits ? dev_logits + (size_t)b0 * C * hw : nullptr;
+    uint8_t* mk = dev_mask ? dev_mask + (size_t)b0 * hw : nullptr;
+    uint8_t* cb = dev_cable ? dev_cable + (size_t)b0 * hw : nullptr;
+    uint8_t* tp = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
+    auto run_conv = [&](ConvLayer& L, bool head) {
+      ConvArgs a{};
       const int H = h >> L.lvl, W = w >> L.lvl;
       a.in0 = L.in.p; a.in1 = L.in2.C ? L.in2.p : nullptr; a.C0 = L.in.C; a.C1 = L.in2.C;
       a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = L.out.p;
@@ -419,10 +427,16 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
       double px = (double)nb * H * W;
       double flops = 2.0 * px * L.cout * L.cin_real * 9;
-      double bytes = px * P * 2.0 * (L.in.C + L.in2.C + L.cout) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
-      char lbl[96];
-      snprintf(lbl, sizeof lbl, "%s|conv3x3<P%d,KC%d,NW%d,MW%d,W%d,pool%d>", L.name.c_str(), P, L.KC, L.NW, L.MW, L.WAVES, (int)L.do_pool);
-      Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, s); });
+      double bytes = px * P * 2.0 * (L.in.C + L.in2.C + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+      if (head) {
+        a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
+        a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tp;
+        flops += 2.0 * px * 32 * C;
+        bytes += px * ((lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
+      }
+      char lbl[112];
+      snprintf(lbl, sizeof lbl, "%s%s|conv3x3<P%d,KC%d,NW%d,MW%d,W%d,pool%d,head%d>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, (int)L.do_pool, (int)head);
+      Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, head, s); });
     };
     auto run_up = [&](int l, const Tensor& low) {
       const int H = h >> l, W = w >> l;
@@ -438,19 +452,15 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       });
     };
     size_t li = 0;
-    for (int l = 0; l < 5; ++l) { run_conv(e->convs[li]); ++li; run_conv(e->convs[li]); ++li; }
+    for (int l = 0; l < 5; ++l) { run_conv(e->convs[li], false); ++li; run_conv(e->convs[li], false); ++li; }
     for (int l = 3; l >= 0; --l) {
       run_up(l, l == 3 ? e->x[4] : e->d[l + 1]);
-      run_conv(e->convs[li]); ++li;
-      run_conv(e->convs[li]); ++li;
+      run_conv(e->convs[li], false); ++li;
+      run_conv(e->convs[li], l == 0 && !e->keep_all); ++li;
     }
-    // head
-    {
+    // head as its own kernel only in debug mode (normally fused into conv0_4.conv2's epilogue)
+    if (e->keep_all) {
       size_t total = (size_t)nb * hw;
-      float* lg = dev_logits ? dev_logits + (size_t)b0 * C * hw : nullptr;
-      uint8_t* mk = dev_mask ? dev_mask + (size_t)b0 * hw : nullptr;
-      uint8_t* cb = dev_cable ? dev_cable + (size_t)b0 * hw : nullptr;
-      uint8_t* tp = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
       double bytes = (double)total * (P * 64 + (lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
       Lx.run(P == 2 ? "final+argmax|head_argmax<P2>" : "final+argmax|head_argmax<P1>", 2.0 * total * 32 * C, bytes, [&] {
         if (P == 2) hipLaunchKernelGGL(head_argmax_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, e->d[0].p, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
@@ -492,6 +502,12 @@ int unetpp_profile_work(const unetpp_engine* e, int i, double* flops, double* by
 }
 
 // ---- debug -------------------------------------------------------------------------------------
+int unetpp_debug_keep_intermediates(unetpp_engine* e, int on) {
+  if (!e) return UNETPP_E_INVALID;
+  e->keep_all = on != 0;
+  return UNETPP_OK;
+}
+
 long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out, size_t max_floats) {
   if (!e || !name || !host_out) return UNETPP_E_INVALID;
   if (e->last_b == 0) return fail(e, UNETPP_E_STATE, "debug_read before forward");
@@ -503,6 +519,7 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
     else if (l >= 0 && l <= 3 && j == 4 - l) t = &e->d[l];
   }
   if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
+  if (t == &e->d[0] && !e->keep_all) return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   int nb = e->last_b % e->mb == 0 ? std::min(e->mb, e->last_b) : e->last_b % e->mb;
   const int H = e->last_h >> t->lvl, W = e->last_w >> t->lvl;

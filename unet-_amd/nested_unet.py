@@ -224,6 +224,10 @@ class NestedUNet:
             out.append((lib.unetpp_profile_name(self._handle, i).decode(), float(ms[i]), fl.value, by.value))
         return out
 
+    def debug_keep_intermediates(self, on: bool = True):
+        """Materialise x0_4 and run the head unfused (needed before debug_activation('x0_4'))."""
+        _lib.load().unetpp_debug_keep_intermediates(self._handle, 1 if on else 0)
+
     def debug_activation(self, name: str, b: int, h: int, w: int) -> np.ndarray:
         """float32 [b,C,h',w'] copy of an intermediate node ('x0_0'..'x4_0','x3_1','x2_2','x1_3','x0_4')."""
         lvl = int(name[1])
