@@ -242,8 +242,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     for (int i = tid; i < a.head_C; i += NT) head_lds[a.head_C * 32 + i] = a.head_b[i];
   }
 
+  // ---- tile order: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch), hence an L2.
+  // Give each XCD a contiguous run of tiles per round, so that the nct channel tiles of one pixel
+  // tile and spatially neighbouring pixel tiles (shared halo) are fetched into the same L2.
+  // Speed only: any placement gives the same result.
+  const int G = (int)gridDim.x;
+  const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+
   // ---- first tile: chunk 0 -> buffer 0
-  int tile = blockIdx.x;
+  int tile = slot;
   if (tile >= total_tiles) return;
   decode(tile, cur_n, cur_y0, cur_x0, cur_ct);
   setup_sources(cur_n, cur_y0, cur_x0, cur_ct);
