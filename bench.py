@@ -161,11 +161,27 @@ def main():
         a[0] += ms; a[1] += fl; a[2] += by; a[3] += 1
     dom = max(agg.items(), key=lambda kv: kv[1][0]) if agg else None
     roofline = None
+    pmc = {}
+    try:   # HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/README.md), if present
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        if files:
+            pmc = json.load(open(files[-1]))["kernels"]
+            pmc_src = os.path.basename(files[-1])
+    except Exception:
+        pmc = {}
     if dom:
         k, (ms, fl, by, cnt) = dom
         tf = fl / (ms * 1e-3) / 1e12
+        mfma_mult = 3.0 if args.precision == "exact" else 1.0      # exact mode issues 3 MFMAs per product
+        traffic = pmc[k]["hbm_bytes_per_launch"] if (k in pmc and args.precision == "exact" and (C, H, W, B) == (3, 512, 512, 16)) else None
         roofline = {"bound": "mfma", "kernel": k, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / cnt, "launches": cnt,
+                    "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_source": (f"profiles/{pmc_src}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
+                                       if traffic is not None else None),
+                    "algorithmic_bytes_per_launch": by / cnt,
+                    "mfma_issued_tflops": tf * mfma_mult, "mfma_issued_frac": tf * mfma_mult / MFMA_F16_PEAK_TFLOPS,
+                    "avg_launch_ms": ms / cnt, "launches": cnt,
                     "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                     "algorithmic_hbm_gbs": by / (ms * 1e-3) / 1e9,
                     "time_share": ms / sum(v[0] for v in agg.values())}

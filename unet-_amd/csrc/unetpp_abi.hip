@@ -405,7 +405,7 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       const char* src = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
       size_t total = (size_t)nb * hw;
       double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
-      Lx.run(P == 2 ? "convert_input|convert_input<P2>" : "convert_input|convert_input<P1>", 0, bytes, [&] {
+      Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
         if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, e->in8.p);
         else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, e->in8.p);
         return hipSuccess;
@@ -435,7 +435,7 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
         bytes += px * ((lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
       }
       char lbl[112];
-      snprintf(lbl, sizeof lbl, "%s%s|conv3x3<P%d,KC%d,NW%d,MW%d,W%d,pool%d,head%d>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, (int)L.do_pool, (int)head);
+      snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
       Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, head, s); });
     };
     auto run_up = [&](int l, const Tensor& low) {
@@ -444,7 +444,7 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       double px = (double)nb * H * W;
       double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
       char nm[64];
-      snprintf(nm, sizeof nm, "up%d|upsample2x<P%d>", l, P);
+      snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", l, P);
       Lx.run(nm, px * low.C * 8, bytes, [&] {
         if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
         else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
@@ -462,7 +462,7 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     if (e->keep_all) {
       size_t total = (size_t)nb * hw;
       double bytes = (double)total * (P * 64 + (lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
-      Lx.run(P == 2 ? "final+argmax|head_argmax<P2>" : "final+argmax|head_argmax<P1>", 2.0 * total * 32 * C, bytes, [&] {
+      Lx.run(P == 2 ? "final+argmax|head_argmax_kernel<2>" : "final+argmax|head_argmax_kernel<1>", 2.0 * total * 32 * C, bytes, [&] {
         if (P == 2) hipLaunchKernelGGL(head_argmax_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, e->d[0].p, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
         else hipLaunchKernelGGL(head_argmax_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, e->d[0].p, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
         return hipSuccess;
