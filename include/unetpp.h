@@ -57,6 +57,9 @@ typedef struct unetpp_config {
   int precision;     /* UNETPP_PREC_* */
   int device;        /* HIP device ordinal: model.to(device)   infer_two_stage_burr.py:214 */
   int micro_batch;   /* frames pushed through the network per pass (0 = max_batch) */
+  int streams;       /* passes in flight at once (1..4): each gets its own activation area and an internal
+                        HIP stream, forked from / joined to the caller's stream with events, so HBM-bound
+                        and MFMA-bound kernels of different passes overlap; 0 or 1 = serial */
 } unetpp_config;
 
 /* NestedUNet.__init__ + .to(device) (src/models/unetpp.py:40-91, infer_two_stage_burr.py:214):

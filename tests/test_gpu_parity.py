@@ -21,11 +21,11 @@ def torch_cuda():
     return torch
 
 
-def make_model(C, ds, wseed, precision, syn, max_batch, hw, micro_batch=0):
+def make_model(C, ds, wseed, precision, syn, max_batch, hw, micro_batch=0, streams=1):
     from unet_amd.nested_unet import NestedUNet
     sd = syn.make_state_dict(C, 3, ds, wseed)
     m = NestedUNet(C, deep_supervision=ds, precision=precision, max_batch=max_batch, max_hw=hw,
-                   micro_batch=micro_batch).to("cuda:0")
+                   micro_batch=micro_batch, streams=streams).to("cuda:0")
     m.load_state_dict(sd, strict=True)
     return m.eval(), sd
 
@@ -131,9 +131,11 @@ def test_batch_and_microbatch_invariance(torch_cuda, syn):
     x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
     full, _ = make_model(3, True, 2, "exact", syn, 5, (64, 64))
     micro, _ = make_model(3, True, 2, "exact", syn, 5, (64, 64), micro_batch=2)
-    a = full(x); b = micro(x); c = full(x[3:4])
+    multi, _ = make_model(3, True, 2, "exact", syn, 5, (64, 64), micro_batch=1, streams=3)
+    a = full(x); b = micro(x); c = full(x[3:4]); d = multi(x); d2 = multi(x)
     torch.cuda.synchronize()
     assert torch.equal(a, b)                 # micro-batching never changes results
+    assert torch.equal(a, d) and torch.equal(a, d2)   # nor do concurrent passes on internal streams
     assert torch.equal(a[3:4], c)            # a frame's result does not depend on its batch
 
 

@@ -42,7 +42,7 @@ def test_create_without_gpu_fails_loudly():
         pytest.skip("GPU present")
     from unet_amd import _lib
     lib = _lib.load()
-    cfg = _lib.Config(3, 3, 1, 32, 32, 0, 0, 0)
+    cfg = _lib.Config(3, 3, 1, 32, 32, 0, 0, 0, 1)
     h = ctypes.c_void_p()
     rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc != 0 and not h.value

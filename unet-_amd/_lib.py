@@ -29,7 +29,7 @@ IN_F32_NCHW, IN_U8_NHWC_BGR = 0, 1
 class Config(ctypes.Structure):
     _fields_ = [("num_classes", ctypes.c_int), ("in_channels", ctypes.c_int), ("max_batch", ctypes.c_int),
                 ("max_h", ctypes.c_int), ("max_w", ctypes.c_int), ("precision", ctypes.c_int),
-                ("device", ctypes.c_int), ("micro_batch", ctypes.c_int)]
+                ("device", ctypes.c_int), ("micro_batch", ctypes.c_int), ("streams", ctypes.c_int)]
 
 
 def _stale() -> bool:

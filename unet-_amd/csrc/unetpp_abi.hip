@@ -78,6 +78,12 @@ struct unetpp_engine {
   int prof_used = 0;
   int last_b = 0, last_h = 0, last_w = 0;
   bool keep_all = false;   // debug: materialise x0_4 and run the head as its own kernel
+  // concurrent micro-batches: `nstreams` copies of the activation area, one internal stream each
+  int nstreams = 1;
+  size_t act_bytes = 0;          // size of one activation area (slot)
+  size_t last_slot_off = 0;
+  hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_start = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -231,6 +237,8 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   e->cfg = *cfg;
   e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
+  e->nstreams = std::max(1, std::min(4, cfg->streams));
+  if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
   const int P = e->P;
 
   // ---- tensor plan (sizes for micro-batch x max_h x max_w)
@@ -247,6 +255,9 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   for (int l = 0; l < 5; ++l) { plan(e->xa[l], NB[l], l); plan(e->x[l], NB[l], l); }
   for (int l = 0; l < 4; ++l) plan(e->pooled[l], NB[l], l + 1);
   for (int l = 0; l < 4; ++l) { plan(e->up[l], NB[l + 1], l); plan(e->da[l], NB[l], l); plan(e->d[l], NB[l], l); }
+
+  e->act_bytes = align_up(total, 4096);
+  total = e->act_bytes * e->nstreams;
 
   // ---- conv layers in forward order; canonical blob offsets
   size_t off = 0;
@@ -313,6 +324,13 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
       e->convs[i].in = e->da[l]; e->convs[i].out = e->d[l]; ++i;
     }
   }
+  if (e->nstreams > 1) {
+    for (int i = 0; i < e->nstreams; ++i) {
+      HIP_TRY(nullptr, hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking));
+      HIP_TRY(nullptr, hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming));
+    }
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
+  }
   *out = e;
   return UNETPP_OK;
 }
@@ -321,6 +339,8 @@ void unetpp_destroy(unetpp_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   for (auto& r : e->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+  for (int i = 0; i < 4; ++i) { if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]); if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]); }
+  if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->arena) (void)hipFree(e->arena);
   delete e;
 }
@@ -392,22 +412,34 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     return fail(e, UNETPP_E_INVALID, "Sizes of tensors must match: H=%d W=%d must be positive multiples of 16", h, w);
   if (h > e->cfg.max_h || w > e->cfg.max_w) return fail(e, UNETPP_E_INVALID, "shape %dx%d exceeds engine maximum %dx%d", h, w, e->cfg.max_h, e->cfg.max_w);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t user_stream = (hipStream_t)stream;
+  hipStream_t s = user_stream;
   const int P = e->P, C = e->cfg.num_classes;
+  const bool multi = e->nstreams > 1 && batch > e->mb;
+  if (multi) {   // fork: the internal streams start after everything already queued on the caller's stream
+    HIP_TRY(e, hipEventRecord(e->ev_start, user_stream));
+    for (int i = 0; i < e->nstreams; ++i) HIP_TRY(e, hipStreamWaitEvent(e->streams[i], e->ev_start, 0));
+  }
   e->last_b = batch; e->last_h = h; e->last_w = w;
   Launcher Lx{e, s};
+  int pass = 0;
   const size_t hw = (size_t)h * w;
 
-  for (int b0 = 0; b0 < batch; b0 += e->mb) {
+  for (int b0 = 0; b0 < batch; b0 += e->mb, ++pass) {
     const int nb = std::min(e->mb, batch - b0);
+    const int slot = multi ? pass % e->nstreams : 0;
+    if (multi) { s = e->streams[slot]; Lx.s = s; }
+    const size_t slot_off = (size_t)slot * e->act_bytes;
+    e->last_slot_off = slot_off;
+    auto sp = [&](const Tensor& t) { return (half_t*)((char*)t.p + slot_off); };
     // 1. input conversion
     {
       const char* src = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
       size_t total = (size_t)nb * hw;
       double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
       Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, e->in8.p);
-        else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, e->in8.p);
+        if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, sp(e->in8));
+        else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, sp(e->in8));
         return hipSuccess;
       });
     }
@@ -418,9 +450,9 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     auto run_conv = [&](ConvLayer& L, bool head) {
       ConvArgs a{};
       const int H = h >> L.lvl, W = w >> L.lvl;
-      a.in0 = L.in.p; a.in1 = L.in2.C ? L.in2.p : nullptr; a.C0 = L.in.C; a.C1 = L.in2.C;
-      a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = L.out.p;
-      a.pool_out = L.do_pool ? L.pool.p : nullptr;
+      a.in0 = sp(L.in); a.in1 = L.in2.C ? sp(L.in2) : nullptr; a.C0 = L.in.C; a.C1 = L.in2.C;
+      a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = sp(L.out);
+      a.pool_out = L.do_pool ? sp(L.pool) : nullptr;
       a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
       const int TH = L.WAVES * L.MW;
       a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
@@ -446,8 +478,8 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       char nm[64];
       snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", l, P);
       Lx.run(nm, px * low.C * 8, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
-        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, low.p, low.C, nb, H, W, e->up[l].p);
+        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
+        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
         return hipSuccess;
       });
     };
@@ -463,12 +495,18 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       size_t total = (size_t)nb * hw;
       double bytes = (double)total * (P * 64 + (lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
       Lx.run(P == 2 ? "final+argmax|head_argmax_kernel<2>" : "final+argmax|head_argmax_kernel<1>", 2.0 * total * 32 * C, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(head_argmax_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, e->d[0].p, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
-        else hipLaunchKernelGGL(head_argmax_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, e->d[0].p, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
+        if (P == 2) hipLaunchKernelGGL(head_argmax_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(e->d[0]), e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
+        else hipLaunchKernelGGL(head_argmax_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(e->d[0]), e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
         return hipSuccess;
       });
     }
     if (Lx.rc) return Lx.rc;
+  }
+  if (multi) {   // join: the caller's stream continues after every internal stream has drained
+    for (int i = 0; i < e->nstreams; ++i) {
+      HIP_TRY(e, hipEventRecord(e->ev_done[i], e->streams[i]));
+      HIP_TRY(e, hipStreamWaitEvent(user_stream, e->ev_done[i], 0));
+    }
   }
   return Lx.rc;
 }
@@ -528,8 +566,8 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   float* tmp = nullptr;
   HIP_TRY(e, hipDeviceSynchronize());
   HIP_TRY(e, hipMalloc((void**)&tmp, total * sizeof(float)));
-  if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, t->p, nb, t->C, H, W, tmp);
-  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, t->p, nb, t->C, H, W, tmp);
+  if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, (const half_t*)((const char*)t->p + e->last_slot_off), nb, t->C, H, W, tmp);
+  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, (const half_t*)((const char*)t->p + e->last_slot_off), nb, t->C, H, W, tmp);
   hipError_t st = hipMemcpy(host_out, tmp, total * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(tmp);
   if (st != hipSuccess) return fail(e, UNETPP_E_HIP, "debug copy: %s", hipGetErrorString(st));

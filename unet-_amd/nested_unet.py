@@ -23,7 +23,7 @@ from . import _lib, packing
 class NestedUNet:
     def __init__(self, num_classes: int, input_channels: int = 3, deep_supervision: bool = True,
                  pretrained_encoder: bool = False, *, precision: str = "exact", max_batch: int = 16,
-                 max_hw=(512, 512), micro_batch: int = 0) -> None:
+                 max_hw=(512, 512), micro_batch: int = 0, streams: int = 1) -> None:
         if pretrained_encoder:
             # unetpp.py:52-65 swaps in a torchvision ResNet50 and downloads ImageNet weights; no
             # north-star caller uses it (infer_two_stage_burr.py:214) and there is no network here.
@@ -40,6 +40,7 @@ class NestedUNet:
         self._max_batch = int(max_batch)
         self._max_hw = (int(max_hw[0]), int(max_hw[1]))
         self._micro_batch = int(micro_batch)
+        self._streams = int(streams)
         self._device_index: Optional[int] = None
         self._handle = None
         self._blob: Optional[np.ndarray] = None      # canonical weights (host copy, re-uploaded if the engine is rebuilt)
@@ -119,7 +120,7 @@ class NestedUNet:
         lib = _lib.load()
         cfg = _lib.Config(self.num_classes, self.input_channels, self._max_batch, self._max_hw[0], self._max_hw[1],
                           _lib.PREC_EXACT if self.precision == "exact" else _lib.PREC_FAST, self._device_index,
-                          self._micro_batch)
+                          self._micro_batch, self._streams)
         handle = ctypes.c_void_p()
         rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(handle))
         if rc != 0:
