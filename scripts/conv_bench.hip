@@ -14,17 +14,17 @@ template <int P, int KC, int NW, int MW, int WV>
 float run(ConvArgs a, int reps) {
   using C = ConvCfg<P, KC, NW, MW, WV>;
   auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WV, false>;
-  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 8192));
   a.tiles_x = (a.W + 31) / 32; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
   a.nchunks = (a.C0 + KC - 1) / KC + a.C1 / KC;
   int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   int per_cu = std::max(1, std::min(2, (160 * 1024) / C::LDS_BYTES));
   dim3 grid(std::min(total, 256 * per_cu));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, 0, a);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES + a.Cout * 8, 0, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES, 0, a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(C::NT), C::LDS_BYTES + a.Cout * 8, 0, a);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("grid %u LDS %d\n", grid.x, C::LDS_BYTES);

@@ -235,7 +235,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       }
   };
 
-  float* head_lds = (float*)(smem + C::LDS_BYTES);   // HEAD only: [C][32] weights then [C] biases
+  // per-channel (scale, bias) of the whole layer staged once per workgroup: the epilogue then reads them
+  // from LDS (broadcast reads) instead of exposing a global-load latency per tile
+  float2* sb_lds = (float2*)(smem + C::LDS_BYTES);
+  for (int i = tid; i < a.Cout; i += NT) sb_lds[i] = make_float2(a.scale[i], a.bias[i]);
+  float* head_lds = (float*)(smem + C::LDS_BYTES + a.Cout * 8);   // HEAD only: [C][32] weights then [C] biases
   if (HEAD) {
     static_assert(!HEAD || (NW == 1 && !POOL), "the fused head needs all 32 channels of x0_4 in one tile");
     for (int i = tid; i < a.head_C * 32; i += NT) head_lds[i] = a.head_w[i];
@@ -372,9 +376,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float sc = a.scale[co], bi = a.bias[co];
+          const float2 sb = sb_lds[co];
 #pragma unroll
-          for (int m = 0; m < MW; ++m) v[m][r] = fmaxf(acc[m][j][r] * sc + bi, 0.f);
+          for (int m = 0; m < MW; ++m) v[m][r] = fmaxf(acc[m][j][r] * sb.x + sb.y, 0.f);
         }
         if (!HEAD) {
 #pragma unroll

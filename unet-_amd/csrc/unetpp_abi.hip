@@ -53,7 +53,8 @@ struct ConvLayer {
 struct ProfRec {
   std::string name;
   double flops = 0, bytes = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int ev0 = -1, ev1 = -1;   // indices into the engine's event pool: launches on one stream are back to
+                            // back, so a launch's start event is the previous launch's end event
 };
 
 }  // namespace
@@ -76,6 +77,10 @@ struct unetpp_engine {
   bool prof_on = false;
   std::vector<ProfRec> prof;
   int prof_used = 0;
+  std::vector<hipEvent_t> evpool;
+  int ev_used = 0;
+  int prof_prev_ev = -1;          // end event of the previous launch on the same stream, -1 = none
+  hipStream_t prof_prev_stream = nullptr;
   int last_b = 0, last_h = 0, last_w = 0;
   bool keep_all = false;   // debug: materialise x0_4 and run the head as its own kernel
   // concurrent micro-batches: `nstreams` copies of the activation area, one internal stream each
@@ -122,7 +127,7 @@ int g_num_cus = 256;
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
 hipError_t launch_conv_k(const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
-  const int lds = C::LDS_BYTES + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
+  const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
@@ -183,20 +188,32 @@ struct Launcher {
   void run(const std::string& name, double flops, double bytes, F&& f) {
     if (rc) return;
     ProfRec* r = nullptr;
-    if (e->prof_on) {
-      if ((size_t)e->prof_used >= e->prof.size()) {
-        ProfRec nr;
-        (void)hipEventCreate(&nr.e0);
-        (void)hipEventCreate(&nr.e1);
-        e->prof.push_back(nr);
+    auto new_event = [&]() {
+      if ((size_t)e->ev_used >= e->evpool.size()) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        e->evpool.push_back(ev);
       }
+      return e->ev_used++;
+    };
+    if (e->prof_on) {
+      if ((size_t)e->prof_used >= e->prof.size()) e->prof.push_back(ProfRec());
       r = &e->prof[e->prof_used++];
       r->name = name; r->flops = flops; r->bytes = bytes;
-      (void)hipEventRecord(r->e0, s);
+      if (e->prof_prev_ev >= 0 && e->prof_prev_stream == s) {
+        r->ev0 = e->prof_prev_ev;
+      } else {
+        r->ev0 = new_event();
+        (void)hipEventRecord(e->evpool[r->ev0], s);
+      }
     }
     hipError_t st = f();
     if (st == hipSuccess) st = hipGetLastError();
-    if (r) (void)hipEventRecord(r->e1, s);
+    if (r) {
+      r->ev1 = new_event();
+      (void)hipEventRecord(e->evpool[r->ev1], s);
+      e->prof_prev_ev = r->ev1; e->prof_prev_stream = s;
+    }
     if (st != hipSuccess) rc = fail(e, UNETPP_E_HIP, "launch %s: %s", name.c_str(), hipGetErrorString(st));
   }
 };
@@ -338,7 +355,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
 void unetpp_destroy(unetpp_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
-  for (auto& r : e->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+  for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]); if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]); }
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->arena) (void)hipFree(e->arena);
@@ -423,6 +440,7 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
   e->last_b = batch; e->last_h = h; e->last_w = w;
   Launcher Lx{e, s};
   int pass = 0;
+  e->prof_prev_ev = -1;     // other work may sit between two forwards: start a fresh event chain
   const size_t hw = (size_t)h * w;
 
   for (int b0 = 0; b0 < batch; b0 += e->mb, ++pass) {
@@ -516,6 +534,8 @@ int unetpp_profile_enable(unetpp_engine* e, int on) {
   if (!e) return UNETPP_E_INVALID;
   e->prof_on = on != 0;
   e->prof_used = 0;
+  e->ev_used = 0;
+  e->prof_prev_ev = -1;
   return UNETPP_OK;
 }
 int unetpp_profile_count(const unetpp_engine* e) { return e ? e->prof_used : 0; }
@@ -523,8 +543,8 @@ int unetpp_profile_read(unetpp_engine* e, float* ms_out, int n) {
   if (!e || !ms_out) return UNETPP_E_INVALID;
   int m = std::min(n, e->prof_used);
   for (int i = 0; i < m; ++i) {
-    HIP_TRY(e, hipEventSynchronize(e->prof[i].e1));
-    HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->prof[i].e0, e->prof[i].e1));
+    HIP_TRY(e, hipEventSynchronize(e->evpool[e->prof[i].ev1]));
+    HIP_TRY(e, hipEventElapsedTime(&ms_out[i], e->evpool[e->prof[i].ev0], e->evpool[e->prof[i].ev1]));
   }
   return m;
 }
