@@ -115,11 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # one process per GPU; UNETPP_BENCH_SHARE_GPU=1 maps every rank onto the visible GPUs round-robin
+    # (rehearsal of the N>1 control flow on a 1-GPU box, together with UNETPP_DIST_BACKEND=gloo)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if os.environ.get("UNETPP_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+    backend = os.environ.get("UNETPP_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     C, H, W, B = args.classes, args.height, args.width, args.batch
@@ -162,7 +170,7 @@ def main():
         if profile:
             model.profile(False)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, recs

@@ -21,13 +21,15 @@ def broadcast_blob(blob_np, nbytes: int, device, src: int = 0):
     Ranks other than src pass blob_np=None."""
     import torch
     import torch.distributed as dist
+    # RCCL moves device buffers; with the gloo backend (CPU rehearsal) the blob travels through host memory
+    comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     if dist.get_rank() == src:
-        t = torch.from_numpy(np.ascontiguousarray(blob_np)).to(device)
+        t = torch.from_numpy(np.ascontiguousarray(blob_np)).to(comm_dev)
         assert t.numel() == nbytes
     else:
-        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        t = torch.empty(nbytes, dtype=torch.uint8, device=comm_dev)
     dist.broadcast(t, src=src)
-    return t
+    return t.to(device)
 
 
 def load_replicated(model, state_dict_or_none, num_classes: int, in_channels: int = 3, src: int = 0):
