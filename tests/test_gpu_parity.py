@@ -158,3 +158,71 @@ def test_errors(torch_cuda, syn):
     sd7 = syn.make_state_dict(7, 3, True, 0)
     with pytest.raises(RuntimeError, match="size mismatch"):
         m2.load_state_dict(sd7, strict=True)
+
+
+@pytest.mark.parametrize("C,B,H,W", [(3, 1, 16, 16), (3, 3, 16, 80), (7, 2, 80, 16), (3, 2, 112, 144), (7, 1, 32, 224)])
+def test_ragged_shapes_against_oracle(C, B, H, W, torch_cuda, syn, oracle):
+    """Minimum size, single row/column of tiles, widths that are not multiples of the 32-pixel tile
+    (80 = 2.5 tiles, 144 = 4.5), heights that are not multiples of the 16-row tile: oracle on the host."""
+    torch = torch_cuda
+    ds = C == 3
+    frames = syn.make_frames_u8(B, H, W, "uniform", 100 + H + W)
+    x = syn.frames_to_chw_f32(frames)
+    model, sd = make_model(C, ds, 2, "exact", syn, B, (H, W))
+    ref = oracle.torch_forward(sd, x)
+    ref_mask, ref_cable, ref_tape = oracle.masks_from_logits(ref)
+    mask, cable, tape, logits = model.segment(torch.from_numpy(frames).cuda(), return_logits=True, return_class_masks=True)
+    torch.cuda.synchronize()
+    err, flips, unexplained = report(logits.cpu().numpy(), mask.cpu().numpy(), ref, ref_mask, oracle)
+    print(f"C={C} {B}x{H}x{W}: max|dlogit|={err:.3e} flips={flips}")
+    assert err < 2e-5 and unexplained == 0
+    agree = mask.cpu().numpy() == ref_mask
+    assert np.array_equal(cable.cpu().numpy()[agree], ref_cable[agree]) and np.array_equal(tape.cpu().numpy()[agree], ref_tape[agree])
+
+
+def test_config5_1024_exact_vs_oracle_and_batch_invariance(torch_cuda, syn, oracle):
+    """BASELINE config 5 shape (3-class 1024x1024): one frame against the oracle, and the size-independent
+    property that a frame's result does not depend on its position in the batch (bitwise)."""
+    torch = torch_cuda
+    frames = syn.make_frames_u8(3, 1024, 1024, "smooth", 77)
+    x = syn.frames_to_chw_f32(frames)
+    model, sd = make_model(3, True, 2, "exact", syn, 3, (1024, 1024))
+    xt = torch.from_numpy(x).cuda()
+    mask, logits = model.segment(xt, return_logits=True)
+    m1, l1 = model.segment(xt[2:3], return_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(logits[2:3], l1) and torch.equal(mask[2:3], m1)
+    ref = oracle.torch_forward(sd, x[:1])
+    ref_mask, _, _ = oracle.masks_from_logits(ref)
+    err, flips, unexplained = report(logits[:1].cpu().numpy(), mask[:1].cpu().numpy(), ref, ref_mask, oracle)
+    print(f"1024x1024: max|dlogit|={err:.3e} flips={flips}/{ref_mask.size}")
+    assert err < 3e-5 and unexplained == 0 and flips <= 8
+
+
+def test_config4_7class_448x800_batch_properties(torch_cuda, syn):
+    """BASELINE config 4 shape at batch 32 (exact): batch-row invariance and u8-vs-f32 input agreement."""
+    torch = torch_cuda
+    frames = syn.make_frames_u8(32, 448, 800, "smooth", 5)
+    model, _ = make_model(7, False, 0, "exact", syn, 32, (448, 800))
+    fu8 = torch.from_numpy(frames).cuda()
+    mask = model.segment(fu8)
+    m5 = model.segment(fu8[5:6])
+    mf = model.segment(torch.from_numpy(syn.frames_to_chw_f32(frames[30:32])).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(mask[5:6], m5) and torch.equal(mask[30:32], mf)
+    hist = torch.bincount(mask.flatten().long(), minlength=7)
+    assert int((hist > 0).sum()) >= 3 and int(hist.sum()) == 32 * 448 * 800
+
+
+def test_fast_mode_error_is_bounded_and_reported(torch_cuda, syn, oracle):
+    """fast (plain fp16) does not pass the 1e-3 gate; it must stay within its own documented band."""
+    torch = torch_cuda
+    frames = syn.make_frames_u8(2, 128, 160, "smooth", 9)
+    x = syn.frames_to_chw_f32(frames)
+    model, sd = make_model(3, True, 2, "fast", syn, 2, (128, 160))
+    ref = oracle.torch_forward(sd, x)
+    logits = model(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    err = float(np.abs(logits.cpu().numpy() - ref).max())
+    print(f"fast 128x160: max|dlogit|={err:.3e}")
+    assert 1e-5 < err < 3e-2
