@@ -101,6 +101,34 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
                    float* dev_logits, uint8_t* dev_mask, uint8_t* dev_cable, uint8_t* dev_tape,
                    void* stream);
 
+/* ---- probability outputs and thresholded class rules -------------------------
+ * Half of the reference's frame loops do not take a plain argmax: they compute
+ * probs = softmax_np(outputs[0].transpose(1,2,0)) on the host and derive the cable / tape masks with
+ * a thresholded rule.  unetpp_forward_ex runs the softmax (fp32) and the rule in the same epilogue as
+ * the 1x1 head, so neither logits nor probabilities need to leave the GPU. */
+enum {
+  UNETPP_RULE_ARGMAX = 0,        /* (pred==1), (pred==2)                infer_two_stage_burr.py:303-304 */
+  UNETPP_RULE_THRESHOLDED = 1,   /* thresholded_argmax(probs, t_cable, t_tape, bg_margin)
+                                    infer_video_3class_best.py:56-83, infer_video_strict.py:36-63 */
+  UNETPP_RULE_STRICT_BG = 2,     /* strict_threshold_with_bg_check(probs, t_cable, t_tape, bg_margin)
+                                    infer_video_fixed.py:35-83 */
+  UNETPP_RULE_EXCLUSIVE = 3      /* exclusive_threshold(probs, t_cable, t_tape, bg_margin, ct_margin)
+                                    infer_video_robust.py:70-99 */
+};
+
+typedef struct unetpp_outputs {
+  float* dev_logits;     /* float32 [B,C,H,W] or NULL */
+  float* dev_probs;      /* float32 [B,C,H,W] softmax over C, or NULL (the reference builds HxWxC on the host) */
+  uint8_t* dev_mask;     /* uint8 [B,H,W] plain argmax class index, or NULL */
+  uint8_t* dev_cable;    /* uint8 [B,H,W] 0/1 under `rule`, or NULL */
+  uint8_t* dev_tape;     /* uint8 [B,H,W] 0/1 under `rule`, or NULL */
+  int rule;              /* UNETPP_RULE_* (rules 1-3 need num_classes >= 3: bg, cable, tape = classes 0,1,2) */
+  float t_cable, t_tape, bg_margin, ct_margin;
+} unetpp_outputs;
+
+int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w,
+                      const unetpp_outputs* out, void* stream);
+
 /* Bytes of device memory held by the engine (workspace + packed weights). */
 size_t unetpp_workspace_bytes(const unetpp_engine* e);
 

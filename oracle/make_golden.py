@@ -43,6 +43,43 @@ def _import_reference():
     return NestedUNet
 
 
+def _import_rule_scripts():
+    """The thresholded frame loops import cv2 (absent) at module level; their pure-NumPy helpers
+    (softmax_np + the class rules) run fine with an empty cv2 stub.  Nothing else of them is executed
+    (their main() sits under `if __name__ == '__main__'`)."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import importlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    best = importlib.import_module("infer_video_3class_best")
+    strict = importlib.import_module("infer_video_strict")
+    fixed = importlib.import_module("infer_video_fixed")
+    robust = importlib.import_module("infer_video_robust")
+    return best, strict, fixed, robust
+
+
+def rule_payload(mods, logits):
+    """cable/tape masks of every rule family, with the reference's default parameters, per frame."""
+    best, strict, fixed, robust = mods
+    out = {}
+    names = (("thr", lambda p: best.thresholded_argmax(p)), ("thr_strict", lambda p: strict.thresholded_argmax_strict(p)),
+             ("bgcheck", lambda p: fixed.strict_threshold_with_bg_check(p)), ("excl", lambda p: robust.exclusive_threshold(p)),
+             ("excl_loose", lambda p: robust.exclusive_threshold(p, t_cable=0.34, t_tape=0.34, bg_margin=0.0, ct_margin=0.0)))
+    probs_all = []
+    for tag, fn in names:
+        cs, ts = [], []
+        for i in range(logits.shape[0]):
+            probs = best.softmax_np(logits[i].transpose(1, 2, 0))          # infer_video_3class_best.py:197
+            c, t = fn(probs)
+            cs.append(c); ts.append(t)
+            if tag == "thr":
+                probs_all.append(probs)
+        out[f"rule_{tag}_cable"] = np.stack(cs).astype(np.uint8)
+        out[f"rule_{tag}_tape"] = np.stack(ts).astype(np.uint8)
+    out["probs_hwc"] = np.stack(probs_all).astype(np.float32)
+    return out
+
+
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -82,6 +119,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     syn = _load_synthetic()
     NestedUNet = _import_reference()
+    rule_mods = _import_rule_scripts()
     meta_lines = []
 
     # ---- small cases: full logits (+ every intermediate for the smallest one)
@@ -101,6 +139,8 @@ def main():
                        mask_cable=(pred == 1).astype(np.uint8), mask_tape=(pred == 2).astype(np.uint8))
         for k, v in t.items():
             payload["t_" + k] = v.astype(np.float32)
+        if C == 3 and tag != "s_c3_32x32":
+            payload.update(rule_payload(rule_mods, logits))
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **payload)
         hist = np.bincount(pred.ravel(), minlength=C).tolist()
         meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] class_hist={hist} min_margin={margin_of(logits).min():.3e}")

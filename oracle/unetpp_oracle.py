@@ -11,6 +11,9 @@ What is restated (citations are /root/reference paths):
   * torch.cat([skip, up],1)     src/models/unetpp.py:112-116  (skip channels first)
   * final 1x1 conv              src/models/unetpp.py:85,119
   * softmax -> argmax -> uint8, class masks   infer_two_stage_burr.py:299-304
+  *  softmax probabilities + thresholded / strict / exclusive class rules
+                                infer_video_3class_best.py:50-83, infer_video_strict.py:36-63,
+                                infer_video_fixed.py:35-83, infer_video_robust.py:64-99
 
 The arithmetic of conv / batch-norm / bilinear upsampling lives in a third-party dependency of the
 reference, PyTorch (requirements.txt:1 pins only torch>=1.10.0; the container has 2.10.0+rocm7.0).
@@ -161,6 +164,61 @@ def top2_margin(logits: np.ndarray) -> np.ndarray:
     """Per-pixel gap between the largest and second-largest logit (for margin-aware flip accounting)."""
     s = np.sort(logits, axis=1)
     return (s[:, -1] - s[:, -2]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- probability rules (SURVEY §8(f) row 1)
+def softmax_last_np(x):
+    """softmax_np of the thresholded frame loops (infer_video_3class_best.py:50-53, infer_video_robust.py:64-67):
+    exp(x - max) / sum over the LAST axis of an HxWxC float32 array."""
+    e_x = np.exp(x - np.max(x, axis=-1, keepdims=True))
+    return e_x / np.sum(e_x, axis=-1, keepdims=True)
+
+
+def thresholded_argmax_np(probs, t_cable=0.45, t_tape=0.50, bg_margin=0.15):
+    """infer_video_3class_best.py:56-83 (infer_video_strict.py:36-63 is the same rule with defaults 0.60/0.65/0.30)."""
+    bg, cable, tape = probs[..., 0], probs[..., 1], probs[..., 2]
+    winner = np.argmax(probs[..., :3], axis=-1)
+    mask_cable = (winner == 1) & (cable >= t_cable) & ((cable - bg) >= bg_margin)
+    mask_tape = (winner == 2) & (tape >= t_tape) & ((tape - bg) >= bg_margin)
+    return mask_cable.astype(np.uint8), mask_tape.astype(np.uint8)
+
+
+def strict_threshold_with_bg_check_np(probs, t_cable=0.6, t_tape=0.65, bg_margin=0.4):
+    """infer_video_fixed.py:35-83: winner + confidence + background-probability ceiling (the overlap branch is
+    unreachable because `winner` is exclusive)."""
+    bg, cable, tape = probs[..., 0], probs[..., 1], probs[..., 2]
+    winner = np.argmax(probs[..., :3], axis=-1)
+    mask_cable = (winner == 1) & (cable >= t_cable) & (bg <= bg_margin)
+    mask_tape = (winner == 2) & (tape >= t_tape) & (bg <= bg_margin)
+    return mask_cable.astype(np.uint8), mask_tape.astype(np.uint8)
+
+
+def exclusive_threshold_np(probs, t_cable=0.55, t_tape=0.60, bg_margin=0.20, ct_margin=0.10):
+    """infer_video_robust.py:70-99: candidates by confidence and margin over background, then the stronger of
+    cable/tape by ct_margin; remaining overlap (only possible for ct_margin <= 0) goes to the larger probability."""
+    pbg, pc, pt = probs[..., 0], probs[..., 1], probs[..., 2]
+    cand_c = (pc >= t_cable) & (pc >= pbg + bg_margin)
+    cand_t = (pt >= t_tape) & (pt >= pbg + bg_margin)
+    cable = cand_c & (pc >= pt + ct_margin)
+    tape = cand_t & (pt >= pc + ct_margin)
+    overlap = cable & tape
+    if np.any(overlap):
+        cable[overlap] = pc[overlap] >= pt[overlap]
+        tape[overlap] = ~cable[overlap]
+    return cable.astype(np.uint8), tape.astype(np.uint8)
+
+
+RULES = {"thresholded_argmax": thresholded_argmax_np, "strict_bg_check": strict_threshold_with_bg_check_np,
+         "exclusive": exclusive_threshold_np}
+
+
+def rule_masks_from_logits(logits_nchw, rule, **params):
+    """Frame-loop tail of the thresholded scripts for a batch: probs = softmax_np(outputs[i].transpose(1,2,0))
+    (infer_video_3class_best.py:197), then the rule.  Returns (cable, tape, probs[B,H,W,C])."""
+    hwc = np.transpose(logits_nchw.astype(np.float32), (0, 2, 3, 1))
+    probs = softmax_last_np(hwc)
+    c, t = RULES[rule](probs, **params)
+    return c, t, probs
 
 
 # ----------------------------------------------------------------------------- torch CPU restatement

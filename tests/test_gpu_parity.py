@@ -226,3 +226,41 @@ def test_fast_mode_error_is_bounded_and_reported(torch_cuda, syn, oracle):
     err = float(np.abs(logits.cpu().numpy() - ref).max())
     print(f"fast 128x160: max|dlogit|={err:.3e}")
     assert 1e-5 < err < 3e-2
+
+
+@pytest.mark.parametrize("tag", ["s_c3_64x64", "s_c3_128x96"])
+def test_probabilities_and_class_rules(tag, torch_cuda, syn, oracle):
+    """fused softmax + thresholded / strict / exclusive rules against the masks the
+    reference's own functions produced.  A pixel may differ only if one of its probabilities sits within
+    1e-5 of a decision boundary (the fp32 logits differ by ~1e-5 from the CPU's)."""
+    from test_oracle_golden import RULE_CASES
+    torch = torch_cuda
+    g = load_golden(tag)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    frames = syn.make_frames_u8(B, H, W, str(g["kind"]), int(g["fseed"]))
+    model, _ = make_model(3, True, int(g["wseed"]), "exact", syn, B, (H, W))
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    probs = model.predict_proba(x)
+    torch.cuda.synchronize()
+    ref_p = np.transpose(g["probs_hwc"], (0, 3, 1, 2))
+    perr = float(np.abs(probs.cpu().numpy() - ref_p).max())
+    print(f"{tag}: max|dprob|={perr:.3e}")
+    assert perr < 1e-5
+    p0, p1, p2 = ref_p[:, 0], ref_p[:, 1], ref_p[:, 2]
+    for key, rule, params in RULE_CASES:
+        cable, tape = model.segment_thresholded(x, rule=rule, **params)
+        torch.cuda.synchronize()
+        cable, tape = cable.cpu().numpy(), tape.cpu().numpy()
+        diff = (cable != g[f"rule_{key}_cable"]) | (tape != g[f"rule_{key}_tape"])
+        # distance of each pixel to the nearest decision boundary of the rules
+        tc, tt, bgm = params["t_cable"], params["t_tape"], params["bg_margin"]
+        ctm = params.get("ct_margin", 0.0)
+        d = np.minimum.reduce([np.abs(p1 - tc), np.abs(p2 - tt), np.abs(p1 - p0 - bgm), np.abs(p2 - p0 - bgm),
+                               np.abs(p0 - bgm), np.abs(p1 - p2 - ctm), np.abs(p2 - p1 - ctm), np.abs(p1 - p2),
+                               np.abs(p1 - p0), np.abs(p2 - p0)])
+        print(f"  {key}: differing pixels {int(diff.sum())}")
+        assert not (diff & (d > 1e-5)).any(), key
+        assert int(diff.sum()) <= 3
+        assert not (cable & tape).any()
+    with pytest.raises(ValueError):
+        model.segment_thresholded(x, rule="nope")

@@ -95,3 +95,23 @@ def test_bilinear_tables(oracle):
     i0, i1, l0, l1 = oracle.bilinear_axis_tables(4, 8)
     assert i0[0] == 0 and l1[0] == 0 and i0[-1] == 3 and i1[-1] == 3     # corners align, last clamps
     assert np.allclose(l0 + l1, 1)
+
+
+RULE_CASES = [("thr", "thresholded_argmax", dict(t_cable=0.45, t_tape=0.50, bg_margin=0.15)),
+              ("thr_strict", "thresholded_argmax", dict(t_cable=0.60, t_tape=0.65, bg_margin=0.30)),
+              ("bgcheck", "strict_bg_check", dict(t_cable=0.6, t_tape=0.65, bg_margin=0.4)),
+              ("excl", "exclusive", dict(t_cable=0.55, t_tape=0.60, bg_margin=0.20, ct_margin=0.10)),
+              ("excl_loose", "exclusive", dict(t_cable=0.34, t_tape=0.34, bg_margin=0.0, ct_margin=0.0))]
+
+
+@pytest.mark.parametrize("tag", ["s_c3_64x64", "s_c3_128x96"])
+def test_probability_rules_match_reference_scripts(tag, oracle):
+    """softmax_np + the three rule families, pinned by masks the reference's own functions produced
+    (infer_video_3class_best / _strict / _fixed / _robust, imported with a cv2 stub by make_golden.py)."""
+    g = load_golden(tag)
+    for key, rule, params in RULE_CASES:
+        cable, tape, probs = oracle.rule_masks_from_logits(g["logits"], rule, **params)
+        assert np.array_equal(cable, g[f"rule_{key}_cable"]), key
+        assert np.array_equal(tape, g[f"rule_{key}_tape"]), key
+        assert not (cable & tape).any()
+    np.testing.assert_allclose(probs, g["probs_hwc"], rtol=0, atol=1e-7)

@@ -17,7 +17,7 @@ HEADERS = ["conv3x3_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include"
 # every symbol include/unetpp.h declares
 ABI_SYMBOLS = [
     "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
-    "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_workspace_bytes",
+    "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_forward_ex", "unetpp_workspace_bytes",
     "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
     "unetpp_profile_work", "unetpp_debug_read", "unetpp_debug_keep_intermediates",
 ]
@@ -30,6 +30,16 @@ class Config(ctypes.Structure):
     _fields_ = [("num_classes", ctypes.c_int), ("in_channels", ctypes.c_int), ("max_batch", ctypes.c_int),
                 ("max_h", ctypes.c_int), ("max_w", ctypes.c_int), ("precision", ctypes.c_int),
                 ("device", ctypes.c_int), ("micro_batch", ctypes.c_int), ("streams", ctypes.c_int)]
+
+
+RULES = {"argmax": 0, "thresholded_argmax": 1, "strict_bg_check": 2, "exclusive": 3}
+
+
+class Outputs(ctypes.Structure):
+    _fields_ = [("dev_logits", ctypes.c_void_p), ("dev_probs", ctypes.c_void_p), ("dev_mask", ctypes.c_void_p),
+                ("dev_cable", ctypes.c_void_p), ("dev_tape", ctypes.c_void_p), ("rule", ctypes.c_int),
+                ("t_cable", ctypes.c_float), ("t_tape", ctypes.c_float), ("bg_margin", ctypes.c_float),
+                ("ct_margin", ctypes.c_float)]
 
 
 def _stale() -> bool:
@@ -74,6 +84,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_load_weights.argtypes = [vp, vp, cs]; lib.unetpp_load_weights.restype = ci
     lib.unetpp_load_weights_device.argtypes = [vp, vp, cs, vp]; lib.unetpp_load_weights_device.restype = ci
     lib.unetpp_forward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]; lib.unetpp_forward.restype = ci
+    lib.unetpp_forward_ex.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(Outputs), vp]; lib.unetpp_forward_ex.restype = ci
     lib.unetpp_workspace_bytes.argtypes = [vp]; lib.unetpp_workspace_bytes.restype = cs
     lib.unetpp_profile_enable.argtypes = [vp, ci]; lib.unetpp_profile_enable.restype = ci
     lib.unetpp_profile_count.argtypes = [vp]; lib.unetpp_profile_count.restype = ci

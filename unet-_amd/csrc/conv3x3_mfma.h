@@ -59,7 +59,34 @@ struct ConvArgs {
   uint8_t* mask;         // [N][H][W] or nullptr
   uint8_t* cable;        // or nullptr
   uint8_t* tape;         // or nullptr
+  // probability outputs: softmax over the C logits in fp32 and the class rules the
+  // thresholded frame loops apply to it; rule 0 = plain (pred==1)/(pred==2) of infer_two_stage_burr.py
+  float* probs;          // [N][C][H][W] fp32 or nullptr
+  int rule;              // UNETPP_RULE_*
+  float t_cable, t_tape, bg_margin, ct_margin;
 };
+
+// cable/tape decision for one pixel from its class probabilities (p0 = background, p1 = cable, p2 = tape)
+//   1 thresholded_argmax              infer_video_3class_best.py:56-83, infer_video_strict.py:36-63
+//   2 strict_threshold_with_bg_check  infer_video_fixed.py:35-83
+//   3 exclusive_threshold             infer_video_robust.py:70-99
+__device__ __forceinline__ void apply_rule(int rule, float p0, float p1, float p2, float tc, float tt, float bgm,
+                                           float ctm, bool& cable, bool& tape) {
+  const int winner = (p1 > p0) ? ((p2 > p1) ? 2 : 1) : ((p2 > p0) ? 2 : 0);   // np.argmax: first maximum
+  if (rule == 1) {
+    cable = winner == 1 && p1 >= tc && (p1 - p0) >= bgm;
+    tape = winner == 2 && p2 >= tt && (p2 - p0) >= bgm;
+  } else if (rule == 2) {
+    cable = winner == 1 && p1 >= tc && p0 <= bgm;
+    tape = winner == 2 && p2 >= tt && p0 <= bgm;
+  } else {
+    const bool cand_c = p1 >= tc && p1 >= p0 + bgm;
+    const bool cand_t = p2 >= tt && p2 >= p0 + bgm;
+    cable = cand_c && p1 >= p2 + ctm;
+    tape = cand_t && p2 >= p1 + ctm;
+    if (cable && tape) { cable = p1 >= p2; tape = !cable; }
+  }
+}
 
 __host__ __device__ constexpr int conv_kgs(int nhalo) {
   // smallest value >= nhalo*16 that is == 32 (mod 128)
@@ -107,6 +134,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 }
 
 constexpr int HEAD_MAX_CLASSES = 16;
+constexpr int HEAD_FUSED_MAX_CLASSES = 8;   // the fused head keeps all logits in registers
 
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false>
 __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs a) {
@@ -397,22 +425,48 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
             const int gy = cur_y0 + wave * MW + m;
             const bool ok = h == 0 && gy < H && gx < W;
             const size_t pix = (size_t)gy * W + gx;
-            float best = -INFINITY;
-            int besti = 0;
-            for (int c = 0; c < a.head_C; ++c) {
-              float part = 0.f;
+            float lg[HEAD_FUSED_MAX_CLASSES];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) part = fmaf(v[m][r], head_lds[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
-              const float other = __shfl_xor(part, 32, 64);
-              const float s = head_lds[a.head_C * 32 + c] + (h == 0 ? part + other : other + part);   // same order in both lanes
-              if (ok && a.logits) a.logits[((size_t)cur_n * a.head_C + c) * hw + pix] = s;
-              if (s > best) { best = s; besti = c; }
+            for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+              lg[c] = -INFINITY;
+              if (c < a.head_C) {       // uniform branch
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part = fmaf(v[m][r], head_lds[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
+                const float other = __shfl_xor(part, 32, 64);
+                lg[c] = head_lds[a.head_C * 32 + c] + (h == 0 ? part + other : other + part);   // same order in both lanes
+              }
+            }
+            float best = lg[0];
+            int besti = 0;
+#pragma unroll
+            for (int c = 1; c < HEAD_FUSED_MAX_CLASSES; ++c)
+              if (lg[c] > best) { best = lg[c]; besti = c; }        // first maximal class wins
+            bool is_cable = besti == 1, is_tape = besti == 2;
+            if (a.probs || a.rule) {      // uniform: softmax_np = exp(x - max) / sum, fp32
+              float pe[HEAD_FUSED_MAX_CLASSES], sum = 0.f;
+#pragma unroll
+              for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+                pe[c] = (c < a.head_C) ? expf(lg[c] - best) : 0.f;
+                sum += pe[c];
+              }
+#pragma unroll
+              for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+                pe[c] = pe[c] / sum;
+                if (ok && a.probs && c < a.head_C) a.probs[((size_t)cur_n * a.head_C + c) * hw + pix] = pe[c];
+              }
+              if (a.rule) apply_rule(a.rule, pe[0], pe[1], pe[2], a.t_cable, a.t_tape, a.bg_margin, a.ct_margin, is_cable, is_tape);
             }
             if (ok) {
+              if (a.logits) {
+#pragma unroll
+                for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c)
+                  if (c < a.head_C) a.logits[((size_t)cur_n * a.head_C + c) * hw + pix] = lg[c];
+              }
               const size_t o = (size_t)cur_n * hw + pix;
               if (a.mask) a.mask[o] = (uint8_t)besti;
-              if (a.cable) a.cable[o] = besti == 1;
-              if (a.tape) a.tape[o] = besti == 2;
+              if (a.cable) a.cable[o] = is_cable;
+              if (a.tape) a.tape[o] = is_tape;
             }
           }
         }

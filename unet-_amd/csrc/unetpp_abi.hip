@@ -420,7 +420,24 @@ int unetpp_load_weights_device(unetpp_engine* e, const void* dev_blob, size_t by
 
 int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w, float* dev_logits,
                    uint8_t* dev_mask, uint8_t* dev_cable, uint8_t* dev_tape, void* stream) {
+  unetpp_outputs o{};
+  o.dev_logits = dev_logits; o.dev_mask = dev_mask; o.dev_cable = dev_cable; o.dev_tape = dev_tape;
+  o.rule = UNETPP_RULE_ARGMAX;
+  return unetpp_forward_ex(e, dev_input, in_format, batch, h, w, &o, stream);
+}
+
+int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w,
+                      const unetpp_outputs* outp, void* stream) {
   if (!e) return UNETPP_E_INVALID;
+  if (!outp) return fail(e, UNETPP_E_INVALID, "outputs is NULL");
+  float* dev_logits = outp->dev_logits; float* dev_probs = outp->dev_probs;
+  uint8_t* dev_mask = outp->dev_mask; uint8_t* dev_cable = outp->dev_cable; uint8_t* dev_tape = outp->dev_tape;
+  if (outp->rule < UNETPP_RULE_ARGMAX || outp->rule > UNETPP_RULE_EXCLUSIVE) return fail(e, UNETPP_E_INVALID, "unknown rule %d", outp->rule);
+  const bool want_probs = dev_probs != nullptr || outp->rule != UNETPP_RULE_ARGMAX;
+  if (outp->rule != UNETPP_RULE_ARGMAX && e->cfg.num_classes < 3)
+    return fail(e, UNETPP_E_INVALID, "class rules need num_classes >= 3 (bg, cable, tape)");
+  if (want_probs && (e->keep_all || e->cfg.num_classes > HEAD_FUSED_MAX_CLASSES))
+    return fail(e, UNETPP_E_UNSUPPORTED, "probabilities / class rules run only in the fused head (num_classes <= %d, debug keep off)", HEAD_FUSED_MAX_CLASSES);
   if (!dev_input) return fail(e, UNETPP_E_INVALID, "input is NULL");
   if (!e->weights_loaded) return fail(e, UNETPP_E_STATE, "forward before load_weights");
   if (in_format != UNETPP_IN_F32_NCHW && in_format != UNETPP_IN_U8_NHWC_BGR) return fail(e, UNETPP_E_INVALID, "unknown input format %d", in_format);
@@ -465,6 +482,8 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     uint8_t* mk = dev_mask ? dev_mask + (size_t)b0 * hw : nullptr;
     uint8_t* cb = dev_cable ? dev_cable + (size_t)b0 * hw : nullptr;
     uint8_t* tp = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
+    float* pr = dev_probs ? dev_probs + (size_t)b0 * C * hw : nullptr;
+    const bool fuse_head = !e->keep_all && C <= HEAD_FUSED_MAX_CLASSES;
     auto run_conv = [&](ConvLayer& L, bool head) {
       ConvArgs a{};
       const int H = h >> L.lvl, W = w >> L.lvl;
@@ -481,8 +500,10 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
       if (head) {
         a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
         a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tp;
+        a.probs = pr; a.rule = outp->rule;
+        a.t_cable = outp->t_cable; a.t_tape = outp->t_tape; a.bg_margin = outp->bg_margin; a.ct_margin = outp->ct_margin;
         flops += 2.0 * px * 32 * C;
-        bytes += px * ((lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
+        bytes += px * ((lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
       }
       char lbl[112];
       snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
@@ -506,10 +527,10 @@ int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int b
     for (int l = 3; l >= 0; --l) {
       run_up(l, l == 3 ? e->x[4] : e->d[l + 1]);
       run_conv(e->convs[li], false); ++li;
-      run_conv(e->convs[li], l == 0 && !e->keep_all); ++li;
+      run_conv(e->convs[li], l == 0 && fuse_head); ++li;
     }
     // head as its own kernel only in debug mode (normally fused into conv0_4.conv2's epilogue)
-    if (e->keep_all) {
+    if (!fuse_head) {
       size_t total = (size_t)nb * hw;
       double bytes = (double)total * (P * 64 + (lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
       Lx.run(P == 2 ? "final+argmax|head_argmax_kernel<2>" : "final+argmax|head_argmax_kernel<1>", 2.0 * total * 32 * C, bytes, [&] {
@@ -577,7 +598,7 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
     else if (l >= 0 && l <= 3 && j == 4 - l) t = &e->d[l];
   }
   if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
-  if (t == &e->d[0] && !e->keep_all) return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
+  if (t == &e->d[0] && !e->keep_all && e->cfg.num_classes <= HEAD_FUSED_MAX_CLASSES) return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   int nb = e->last_b % e->mb == 0 ? std::min(e->mb, e->last_b) : e->last_b % e->mb;
   const int H = e->last_h >> t->lvl, W = e->last_w >> t->lvl;

@@ -147,7 +147,8 @@ class NestedUNet:
         self._blob = blob_tensor.cpu().numpy()
 
     # ------------------------------------------------------------------ the hot path
-    def _run(self, x, want_logits: bool, want_mask: bool, want_class_masks: bool):
+    def _run(self, x, want_logits: bool, want_mask: bool, want_class_masks: bool, want_probs: bool = False,
+             rule: str = "argmax", params=(0.0, 0.0, 0.0, 0.0)):
         import torch
         if self.training:
             raise RuntimeError("engine is inference-only")
@@ -181,11 +182,17 @@ class NestedUNet:
         mask = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_mask else None
         cable = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_class_masks else None
         tape = torch.empty((b, h, w), dtype=torch.uint8, device=dev) if want_class_masks else None
+        probs = torch.empty((b, self.num_classes, h, w), dtype=torch.float32, device=dev) if want_probs else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = _lib.load().unetpp_forward(self._handle, p(x), fmt, b, h, w, p(logits), p(mask), p(cable), p(tape), stream)
+        if rule not in _lib.RULES:
+            raise ValueError(f"rule must be one of {sorted(_lib.RULES)}")
+        outs = _lib.Outputs(p(logits), p(probs), p(mask), p(cable), p(tape), _lib.RULES[rule], *[float(v) for v in params])
+        rc = _lib.load().unetpp_forward_ex(self._handle, p(x), fmt, b, h, w, ctypes.byref(outs), stream)
         if rc != 0:
             raise RuntimeError(self._err(rc))
+        if want_probs:
+            return logits, mask, cable, tape, probs
         return logits, mask, cable, tape
 
     def forward(self, x):
@@ -202,6 +209,19 @@ class NestedUNet:
         if return_logits:
             out += (logits,)
         return out[0] if len(out) == 1 else out
+
+    def segment_thresholded(self, x, rule: str = "thresholded_argmax", t_cable: float = 0.45, t_tape: float = 0.50,
+                            bg_margin: float = 0.15, ct_margin: float = 0.10, return_probs: bool = False):
+        """The thresholded frame loops' tail on the device: probs = softmax_np(outputs) then
+        `thresholded_argmax` (infer_video_3class_best.py:56-83, infer_video_strict.py:36-63),
+        `strict_bg_check` (infer_video_fixed.py:35-83: bg_margin is the background-probability ceiling) or
+        `exclusive` (infer_video_robust.py:70-99).  Returns (mask_cable, mask_tape[, probs[B,C,H,W]]) on device."""
+        r = self._run(x, False, False, True, return_probs, rule, (t_cable, t_tape, bg_margin, ct_margin))
+        return (r[2], r[3], r[4]) if return_probs else (r[2], r[3])
+
+    def predict_proba(self, x):
+        """softmax(model(x), dim=1) as float32 [B,C,H,W] on the device (one fused pass)."""
+        return self._run(x, False, False, False, True)[4]
 
     # ------------------------------------------------------------------ measurement / debug hooks
     def workspace_bytes(self) -> int:
