@@ -62,7 +62,7 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Input conversion -> [N][H][W][P][8] fp16 (channels 3..7 zero).
+// Input conversion -> [N][1][H][W][P][8] fp16 (one channel block of 8, channels 3..7 zero).
 //   fmt 0: float32 NCHW RGB in [0,1]                    (model(img_tensor), infer_two_stage_burr.py:292-295)
 //   fmt 1: uint8 NHWC BGR: RGB = BGR reversed, /255.0f   (preprocess_image, infer_two_stage_burr.py:122-127)
 template <int P>
@@ -105,16 +105,16 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
 template <int P>
 __global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
                                   half_t* __restrict__ out) {
-  const int CUN = Cu / 8;
+  // tensors are channel-blocked: [N][Cu/16][h][w][P][16]; one thread = 8 channels of one output pixel
+  const int NBLK = Cu / 16;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)N * H * W * CUN;
+  size_t total = (size_t)N * NBLK * H * W * 2;
   if (i >= total) return;
-  int cu = i % CUN;
-  size_t p = i / CUN;
+  const int half8i = i & 1;
+  size_t p = i >> 1;
   int x = p % W; size_t q = p / W;
-  int y = q % H; int n = q / H;
-  half_t* dst = out + p * P * Cu + cu * 8;
-  const int c = cu * 8;
+  int y = q % H; size_t nb = q / H;          // nb = n * NBLK + channel block
+  half_t* dst = out + ((nb * H + y) * W + x) * (size_t)(P * 16) + half8i * 8;
   const int h = H >> 1, w = W >> 1;
   const float sh = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
@@ -123,16 +123,16 @@ __global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N,
   int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
   float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
   float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  const half_t* b = low + (size_t)n * h * w * P * Cu + c;
-  const half_t* p00 = b + ((size_t)(y0 * w + x0) * P) * Cu;
-  const half_t* p01 = b + ((size_t)(y0 * w + x1) * P) * Cu;
-  const half_t* p10 = b + ((size_t)(y1 * w + x0) * P) * Cu;
-  const half_t* p11 = b + ((size_t)(y1 * w + x1) * P) * Cu;
+  const half_t* b = low + nb * (size_t)h * w * (P * 16) + half8i * 8;
+  const half_t* p00 = b + (size_t)(y0 * w + x0) * (P * 16);
+  const half_t* p01 = b + (size_t)(y0 * w + x1) * (P * 16);
+  const half_t* p10 = b + (size_t)(y1 * w + x0) * (P * 16);
+  const half_t* p11 = b + (size_t)(y1 * w + x1) * (P * 16);
   half8 a00 = *(const half8*)p00, a01 = *(const half8*)p01, a10 = *(const half8*)p10, a11 = *(const half8*)p11;
   half8 rh, rl;
   if (P == 2) {
-    half8 b00 = *(const half8*)(p00 + Cu), b01 = *(const half8*)(p01 + Cu);
-    half8 b10 = *(const half8*)(p10 + Cu), b11 = *(const half8*)(p11 + Cu);
+    half8 b00 = *(const half8*)(p00 + 16), b01 = *(const half8*)(p01 + 16);
+    half8 b10 = *(const half8*)(p10 + 16), b11 = *(const half8*)(p11 + 16);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v00 = (float)a00[e] + (float)b00[e], v01 = (float)a01[e] + (float)b01[e];
@@ -143,7 +143,7 @@ __global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N,
       rh[e] = hi; rl[e] = lo;
     }
     *(half8*)dst = rh;
-    *(half8*)(dst + Cu) = rl;
+    *(half8*)(dst + 16) = rl;
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -170,20 +170,23 @@ __global__ void head_argmax_kernel(const half_t* __restrict__ x, const float* __
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t hw = (size_t)H * W, total = (size_t)N * hw;
   if (i >= total) return;
-  const half8* px = (const half8*)(x + i * P * 32);
+  size_t n = i / hw, p = i - n * hw;
   float v[32];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    half8 hi = px[g];
+  for (int blk = 0; blk < 2; ++blk) {            // x0_4 is channel-blocked: [N][2][H][W][P][16]
+    const half8* px = (const half8*)(x + (((n * 2 + blk) * hw + p) * P) * 16);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[g * 8 + e] = (float)hi[e];
-    if (P == 2) {
-      half8 lo = px[4 + g];
+    for (int g = 0; g < 2; ++g) {
+      half8 hi = px[g];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[g * 8 + e] += (float)lo[e];
+      for (int e = 0; e < 8; ++e) v[blk * 16 + g * 8 + e] = (float)hi[e];
+      if (P == 2) {
+        half8 lo = px[2 + g];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[blk * 16 + g * 8 + e] += (float)lo[e];
+      }
     }
   }
-  size_t n = i / hw, p = i - n * hw;
   float best = -INFINITY;
   int besti = 0;
   for (int c = 0; c < C; ++c) {
@@ -198,7 +201,7 @@ __global__ void head_argmax_kernel(const half_t* __restrict__ x, const float* __
   if (tape) tape[i] = besti == 2;
 }
 
-// debug: [N][H][W][P][C] fp16 -> float32 NCHW
+// debug: channel-blocked fp16 -> float32 NCHW
 template <int P>
 __global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, int H, int W, float* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,9 +210,10 @@ __global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, i
   int xx = i % W; size_t t = i / W;
   int y = t % H; t /= H;
   int c = t % C; int n = t / C;
-  const half_t* p = x + (((size_t)(n * H + y) * W + xx) * P) * C + c;
+  const int CB = C < 16 ? C : 16;                 // channel-blocked source: [N][C/CB][H][W][P][CB]
+  const half_t* p = x + ((((size_t)(n * (C / CB) + c / CB) * H + y) * W + xx) * P) * CB + c % CB;
   float v = (float)p[0];
-  if (P == 2) v += (float)p[C];
+  if (P == 2) v += (float)p[CB];
   out[i] = v;
 }
 

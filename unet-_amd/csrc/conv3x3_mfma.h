@@ -15,8 +15,12 @@
 //     computes (bounds / zero padding handled there), written to the other buffer afterwards;
 //   * the weight slab 9 x KC x BN — pre-packed in exactly the order the B fragments are read, so it is
 //     a linear copy done by LDS-DMA (global_load_lds_dwordx4), in flight during the MFMAs.
-// Activation layout in HBM: [N][H][W][P][C] fp16, P = 1 (FAST) or 2 (EXACT: plane 0 = hi, plane 1 = lo,
-// value = hi + lo).  EXACT issues three MFMAs per product (lo*hi, hi*lo, hi*hi) into one fp32 accumulator.
+// Activation layout in HBM: channel-blocked NHWC, [N][C/16][H][W][P][16] fp16 (block of CB = min(16, C)
+// channels; P = 1 (FAST) or 2 (EXACT: plane 0 = hi, plane 1 = lo, value = hi + lo)).  One K-chunk of 16
+// channels is therefore one contiguous 32*P bytes per pixel and consecutive pixels are contiguous: a halo
+// row is one 34 x 32*P-byte run and every fetched 128-byte line is fully used (with plain [pixel][C] each
+// chunk touched 32 of every 64+ bytes and the level-0/1 layers over-read HBM 2-3x: profiles/README.md).
+// EXACT issues three MFMAs per product (lo*hi, hi*lo, hi*hi) into one fp32 accumulator.
 //
 // LDS images (bytes):
 //   halo   [P][KG=KC/8][halo pixel][8 halves]  plane stride KGS == 32 (mod 128): the 8-lane groups of
@@ -39,13 +43,13 @@ typedef __attribute__((ext_vector_type(16))) float float16v;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct ConvArgs {
-  const half_t* in0;     // [N][H][W][P][C0]
-  const half_t* in1;     // [N][H][W][P][C1] or nullptr (then C1 = 0)
+  const half_t* in0;     // [N][C0/CB][H][W][P][CB], CB = min(16, C0)
+  const half_t* in1;     // same layout with C1 channels, or nullptr (then C1 = 0)
   const half_t* wpk;     // packed weights [ct][chunk][P][tap][KG][BN][8]
   const float* scale;    // [Cout] 2^-k undoing the per-channel weight scaling
   const float* bias;     // [Cout] folded conv+BN bias
-  half_t* out;           // [N][H][W][P][Cout]
-  half_t* pool_out;      // [N][H/2][W/2][P][Cout] or nullptr
+  half_t* out;           // [N][Cout/16][H][W][P][16]
+  half_t* pool_out;      // [N][Cout/16][H/2][W/2][P][16] or nullptr
   int N, H, W, C0, C1, Cout;
   int tiles_x, tiles_y;  // spatial tiles per image
   int nct;               // Cout / BN
@@ -188,28 +192,32 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   // Raw buffer loads: one descriptor per source covering image n, per-lane byte offset computed once per
   // tile, the chunk's channel offset in the scalar soffset; pixels outside the image (zero padding) and
   // unused items carry an out-of-range offset and read back zeros — no branches in the K loop.
+  const int cb0 = a.C0 < 16 ? a.C0 : 16;                        // channel block of source 0 (8 only for the input tensor)
+  const unsigned plane_bytes0 = (unsigned)(H * W * P * cb0 * 2);   // one channel block of one image
+  const unsigned plane_bytes1 = (unsigned)(H * W * P * 16 * 2);
   auto setup_sources = [&](int n, int y0, int x0, int ct) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const int pl = plkg[it] >> 8, k8 = plkg[it] & 255;
+      const int pl = plkg[it] >> 8, k8 = plkg[it] & 255;       // k8 = 8 * (k-group inside the chunk)
       const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
       const unsigned pix = (unsigned)((gy * W + gx) * P + pl);
-      voff0[it] = (ok && k8 < a.C0) ? (pix * a.C0 + k8) * 2u : OOB;
-      voff1[it] = ok ? (pix * a.C1 + k8) * 2u : OOB;
+      // k-groups 0,1 of a chunk sit in its first channel block, 2,3 (KC = 32) in the next one
+      voff0[it] = (ok && k8 < a.C0) ? (unsigned)(k8 >> 4) * plane_bytes0 + (pix * cb0 + (k8 & 15)) * 2u : OOB;
+      voff1[it] = ok ? (unsigned)(k8 >> 4) * plane_bytes1 + (pix * 16 + (k8 & 15)) * 2u : OOB;
     }
-    const size_t img = (size_t)n * H * W * P;
-    rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + img * a.C0), 0, (int)img_bytes0, 0x00020000);
-    rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 ? a.in1 + img * a.C1 : a.in0), 0,
+    rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)n * H * W * P * a.C0), 0, (int)img_bytes0, 0x00020000);
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 ? a.in1 + (size_t)n * H * W * P * a.C1 : a.in0), 0,
                                               (int)(a.in1 ? img_bytes1 : 0u), 0x00020000);
     wsrc = (const char*)a.wpk + (size_t)ct * a.nchunks * C::SLAB_BYTES;
   };
 
   u32x4 hv[ITERS];
   auto halo_issue_one = [&](int c, int it) {     // `it` is a compile-time constant at every call site
-    if (c < nch0) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc0, (int)voff0[it], c * KC * 2, 0);
-    else hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, (int)voff1[it], (c - nch0) * KC * 2, 0);
+    // scalar offset = first channel block of the chunk
+    if (c < nch0) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc0, (int)voff0[it], c * (KC / 16) * (int)plane_bytes0, 0);
+    else hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, (int)voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, 0);
   };
   auto halo_commit = [&](char* halo) {
 #pragma unroll
@@ -357,11 +365,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     // the fused 2x2 max-pool (unetpp.py:75) is max(row m=0, row m=1) in-lane and one DPP exchange
     // between neighbouring pixel lanes.  No LDS, no barrier: the stores drain under the next tile's MFMAs.
     {
-      const int Cout = a.Cout;
       const int h = lane >> 5;
       const int gx = cur_x0 + (lane & 31);
-      const size_t img_px = (size_t)cur_n * H * W;
-      auto pack_store = [&](const float (&v)[16], half_t* dst /* -> channel j*32 of the pixel, plane 0 */, bool ok) {
+      const int nbo = a.Cout >> 4;                       // channel blocks of the output tensor
+      // dst -> plane 0 of the pixel in channel block (j*32)/16; blk_stride = halves between channel blocks
+      auto pack_store = [&](const float (&v)[16], half_t* dst, size_t blk_stride, bool ok) {
         unsigned wh[4][2], wl[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -387,12 +395,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
               wl[2 * pi][w2] = r2[0]; wl[2 * pi + 1][w2] = r2[1];
             }
           }
-          if (ok) {
+          if (ok) {      // octet pi*16 + 8h of this 32-channel tile = channel block pi, halves 8h..8h+7
             u32x4 o = {wh[2 * pi][0], wh[2 * pi][1], wh[2 * pi + 1][0], wh[2 * pi + 1][1]};
-            *(u32x4*)(dst + 16 * pi + 8 * h) = o;
+            *(u32x4*)(dst + pi * blk_stride + 8 * h) = o;
             if (P == 2) {
               u32x4 o2 = {wl[2 * pi][0], wl[2 * pi][1], wl[2 * pi + 1][0], wl[2 * pi + 1][1]};
-              *(u32x4*)(dst + Cout + 16 * pi + 8 * h) = o2;
+              *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = o2;
             }
           }
         }
@@ -413,8 +421,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
           for (int m = 0; m < MW; ++m) {
             const int gy = cur_y0 + wave * MW + m;
             const bool ok = gy < H && gx < W;
-            half_t* dst = a.out + ((img_px + (size_t)gy * W + gx) * P) * Cout + cbase;
-            pack_store(v[m], dst, ok);
+            const size_t blk = (size_t)H * W * P * 16;
+            half_t* dst = a.out + ((size_t)cur_n * nbo + (cbase >> 4)) * blk + ((size_t)gy * W + gx) * P * 16;
+            pack_store(v[m], dst, blk, ok);
           }
         } else {
           // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: 16 channels in this lane, the other 16
@@ -482,8 +491,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
           const int Hp = H >> 1, Wp = W >> 1;
           const int py = (cur_y0 >> 1) + wave, px = (cur_x0 >> 1) + ((lane & 31) >> 1);
           const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
-          half_t* dst = a.pool_out + (((size_t)cur_n * Hp * Wp + (size_t)py * Wp + px) * P) * Cout + cbase;
-          pack_store(pv, dst, ok);
+          const size_t blk = (size_t)Hp * Wp * P * 16;
+          half_t* dst = a.pool_out + ((size_t)cur_n * nbo + (cbase >> 4)) * blk + ((size_t)py * Wp + px) * P * 16;
+          pack_store(pv, dst, blk, ok);
         }
       }
     }

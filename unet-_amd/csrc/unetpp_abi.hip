@@ -511,7 +511,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     };
     auto run_up = [&](int l, const Tensor& low) {
       const int H = h >> l, W = w >> l;
-      size_t total = (size_t)nb * H * W * (low.C / 8);
+      size_t total = (size_t)nb * H * W * (low.C / 8);   // one thread per 8 channels of an output pixel
       double px = (double)nb * H * W;
       double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
       char nm[64];
