@@ -102,55 +102,101 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
 // src = dst*(in-1)/(out-1) in fp32, i0 = int(src), i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
 // x is interpolated inside each row first.  The torch.cat([skip, up]) that follows is virtual: the
 // decoder conv reads `skip` and this kernel's output as two sources (conv3x3_mfma.h).
+typedef __attribute__((ext_vector_type(4))) _Float16 half4v;
+
 template <int P>
-__global__ void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
-                                  half_t* __restrict__ out) {
-  // tensors are channel-blocked: [N][Cu/16][h][w][P][16]; one thread = 8 channels of one output pixel
-  const int NBLK = Cu / 16;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)N * NBLK * H * W * 2;
-  if (i >= total) return;
-  const int half8i = i & 1;
-  size_t p = i >> 1;
-  int x = p % W; size_t q = p / W;
-  int y = q % H; size_t nb = q / H;          // nb = n * NBLK + channel block
-  half_t* dst = out + ((nb * H + y) * W + x) * (size_t)(P * 16) + half8i * 8;
+__global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
+                                                         half_t* __restrict__ out) {
+  // Tensors are channel-blocked: [N][Cu/16][h][w][P][16]; a pixel record is 2*P pieces of 16 bytes
+  // ([hi 0-7][hi 8-15][lo 0-7][lo 8-15] in EXACT mode).
+  // grid = (H/2, N * Cu/16): one workgroup produces output rows 2r and 2r+1 of one channel block.  The (at
+  // most three) low-res rows they interpolate are staged ONCE in LDS with full-line loads, so the four
+  // corner reads per output are LDS reads: the vector-memory pipe only sees ~1.75 instructions per output
+  // KiB instead of 10 (the register version was bound by the address coalescer, not by HBM).
+  // One thread stores ONE 16-byte piece, so a wave's store is 1 KiB of consecutive bytes; in EXACT mode the
+  // two threads that share a channel octet (lane ^ 2) each interpolate four of its eight channels (hi+lo
+  // in fp32) and swap halves with one DPP exchange.
+  // Workgroups r, r+8, ... share an XCD (round-robin dispatch): the row-pair index is permuted so that each
+  // XCD owns a contiguous band of rows and neighbouring row pairs find their shared low-res row in its L2.
+  constexpr int PIECES = 2 * P;
+  constexpr int REC = P * 16;                 // halves per pixel record
+  extern __shared__ __attribute__((aligned(16))) char up_smem[];
+  half_t* rows = (half_t*)up_smem;            // [3][w][REC]
+  const int HP = H >> 1;
+  const int rb = blockIdx.x;
+  const int r = (HP % 8 == 0) ? (rb & 7) * (HP >> 3) + (rb >> 3) : rb;
+  const size_t nb = blockIdx.y;               // n * (Cu/16) + channel block
   const int h = H >> 1, w = W >> 1;
   const float sh = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  float fy = sh * (float)y, fx = sw * (float)x;
-  int y0 = (int)fy, x0 = (int)fx;
-  int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-  float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-  float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  const half_t* b = low + nb * (size_t)h * w * (P * 16) + half8i * 8;
-  const half_t* p00 = b + (size_t)(y0 * w + x0) * (P * 16);
-  const half_t* p01 = b + (size_t)(y0 * w + x1) * (P * 16);
-  const half_t* p10 = b + (size_t)(y1 * w + x0) * (P * 16);
-  const half_t* p11 = b + (size_t)(y1 * w + x1) * (P * 16);
-  half8 a00 = *(const half8*)p00, a01 = *(const half8*)p01, a10 = *(const half8*)p10, a11 = *(const half8*)p11;
-  half8 rh, rl;
-  if (P == 2) {
-    half8 b00 = *(const half8*)(p00 + 16), b01 = *(const half8*)(p01 + 16);
-    half8 b10 = *(const half8*)(p10 + 16), b11 = *(const half8*)(p11 + 16);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v00 = (float)a00[e] + (float)b00[e], v01 = (float)a01[e] + (float)b01[e];
-      float v10 = (float)a10[e] + (float)b10[e], v11 = (float)a11[e] + (float)b11[e];
-      float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-      half_t hi, lo;
-      split_f16(v, hi, lo);
-      rh[e] = hi; rl[e] = lo;
+  const int ybase = (int)(sh * (float)(2 * r));          // first low-res row needed
+  {   // stage low-res rows ybase .. ybase+2 (clamped): 3 * w * REC halves, 16 bytes per thread and step
+    const half_t* src = low + nb * (size_t)h * w * REC;
+    const int units_row = w * REC / 8;
+    for (int u = threadIdx.x; u < 3 * units_row; u += blockDim.x) {
+      const int rr = u / units_row, c = u - rr * units_row;
+      const int yy = min(ybase + rr, h - 1);
+      *(u32x4*)(rows + (size_t)u * 8) = *(const u32x4*)(src + ((size_t)yy * w) * REC + (size_t)c * 8);
     }
-    *(half8*)dst = rh;
-    *(half8*)(dst + 16) = rl;
-  } else {
+  }
+  __syncthreads();
+  const int row_items = W * PIECES;           // multiple of 64: every wave is full (DPP exchange below)
+  for (int idx = threadIdx.x; idx < 2 * row_items; idx += blockDim.x) {
+    const int yo = idx >= row_items;           // which of the two output rows (uniform per wave: 64 | row_items)
+    const int id2 = idx - yo * row_items;
+    const int y = 2 * r + yo;
+    const float fy = sh * (float)y;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
+    const int piece = id2 & (PIECES - 1);
+    const int x = id2 / PIECES;
+    const float fx = sw * (float)x;
+    const int x0 = (int)fx;
+    const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
+    const half_t* r0 = rows + (size_t)(y0 - ybase) * w * REC;
+    const half_t* r1 = rows + (size_t)(y1 - ybase) * w * REC;
+    half_t* dst = out + ((nb * H + y) * W + x) * (size_t)REC + piece * 8;
+    if (P == 2) {
+      const int oct = piece & 1, role = piece >> 1;       // role 0 stores hi and computes channels 0-3 of the octet
+      const int e0 = oct * 8 + role * 4;
+      half4v a00 = *(const half4v*)(r0 + x0 * REC + e0), a01 = *(const half4v*)(r0 + x1 * REC + e0);
+      half4v a10 = *(const half4v*)(r1 + x0 * REC + e0), a11 = *(const half4v*)(r1 + x1 * REC + e0);
+      half4v b00 = *(const half4v*)(r0 + x0 * REC + 16 + e0), b01 = *(const half4v*)(r0 + x1 * REC + 16 + e0);
+      half4v b10 = *(const half4v*)(r1 + x0 * REC + 16 + e0), b11 = *(const half4v*)(r1 + x1 * REC + 16 + e0);
+      half4v rh, rl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = ly0 * (lx0 * (float)a00[e] + lx1 * (float)a01[e]) + ly1 * (lx0 * (float)a10[e] + lx1 * (float)a11[e]);
-      rh[e] = (half_t)v;
+      for (int e = 0; e < 4; ++e) {
+        float v00 = (float)a00[e] + (float)b00[e], v01 = (float)a01[e] + (float)b01[e];
+        float v10 = (float)a10[e] + (float)b10[e], v11 = (float)a11[e] + (float)b11[e];
+        float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        half_t hi, lo;
+        split_f16(v, hi, lo);
+        rh[e] = hi; rl[e] = lo;
+      }
+      typedef __attribute__((ext_vector_type(2))) int int2v;
+      const int2v keep = __builtin_bit_cast(int2v, role ? rl : rh);
+      const int2v send = __builtin_bit_cast(int2v, role ? rh : rl);
+      int2v recv;
+      recv[0] = __builtin_amdgcn_mov_dpp(send[0], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]: lane ^ 2
+      recv[1] = __builtin_amdgcn_mov_dpp(send[1], 0x4E, 0xF, 0xF, true);
+      // hi lane: [own channels 0-3 | partner's 4-7]; lo lane: [partner's 0-3 | own 4-7]
+      u32x4 o = role ? u32x4{(unsigned)recv[0], (unsigned)recv[1], (unsigned)keep[0], (unsigned)keep[1]}
+                     : u32x4{(unsigned)keep[0], (unsigned)keep[1], (unsigned)recv[0], (unsigned)recv[1]};
+      *(u32x4*)dst = o;
+    } else {
+      const int e0 = piece * 8;
+      half8 a00 = *(const half8*)(r0 + x0 * REC + e0), a01 = *(const half8*)(r0 + x1 * REC + e0);
+      half8 a10 = *(const half8*)(r1 + x0 * REC + e0), a11 = *(const half8*)(r1 + x1 * REC + e0);
+      half8 rr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = ly0 * (lx0 * (float)a00[e] + lx1 * (float)a01[e]) + ly1 * (lx0 * (float)a10[e] + lx1 * (float)a11[e]);
+        rr[e] = (half_t)v;
+      }
+      *(half8*)dst = rr;
     }
-    *(half8*)dst = rh;
   }
 }
 

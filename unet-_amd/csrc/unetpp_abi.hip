@@ -511,14 +511,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     };
     auto run_up = [&](int l, const Tensor& low) {
       const int H = h >> l, W = w >> l;
-      size_t total = (size_t)nb * H * W * (low.C / 8);   // one thread per 8 channels of an output pixel
       double px = (double)nb * H * W;
       double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
+      // enough waves per LDS byte: the staged rows take 3*(W/2)*P*32 bytes per workgroup
+      const int up_threads = (3 * (W / 2) * P * 32 > 32 * 1024) ? 1024 : (3 * (W / 2) * P * 32 > 12 * 1024 ? 512 : 256);
       char nm[64];
       snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", l, P);
       Lx.run(nm, px * low.C * 8, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
-        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
+        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 2 * 32, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
+        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 1 * 32, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
         return hipSuccess;
       });
     };
