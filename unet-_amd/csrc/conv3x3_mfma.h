@@ -334,8 +334,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       const char* halo = cur;
       const char* slab = cur + C::HALO_BYTES;
       constexpr int NSTEPS = 9 * (KC / 16);
-      constexpr int HPS = (ITERS + NSTEPS - 2) / (NSTEPS - 1);          // halo items issued per step
-      constexpr int DPS = (DMA_PER_WAVE + NSTEPS - 2) / (NSTEPS - 1);   // DMA pieces issued per step
+#ifndef UNETPP_SPREAD_NW1
+#define UNETPP_SPREAD_NW1 3
+#endif
+      // narrow tiles (NW == 1) finish a chunk in ~3.4k cycles, less than a loaded HBM round trip: their
+      // loads go out in the first steps; wide tiles spread them over the whole chunk
+      constexpr int SPREAD = (NW == 1) ? UNETPP_SPREAD_NW1 : NSTEPS - 1;
+      constexpr int HPS = (ITERS + SPREAD - 1) / SPREAD;          // halo items issued per step
+      constexpr int DPS = (DMA_PER_WAVE + SPREAD - 1) / SPREAD;   // DMA pieces issued per step
       Frag f0, f1;
       load_frags(f0, halo, slab, 0);
 #pragma unroll
