@@ -129,6 +129,19 @@ typedef struct unetpp_outputs {
 int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w,
                       const unetpp_outputs* out, void* stream);
 
+/* ---- mask statistics on the device -------------------------------------------
+ * From a uint8 class-index mask [B,H,W] (e.g. the dev_mask of a forward): per-frame class pixel counts
+ * (np.sum(mask_cable) / coverage, infer_two_stage_burr.py:333-340, src/utils/geometry_enhanced.py:151-152) and,
+ * per class and row, the first and last column of that class — the operands of _compute_width_per_row
+ * (geometry_enhanced.py:45-74: width = xs.max() - xs.min() + 1).  The reference's smoothing and
+ * connected-component filtering (cv2) stay on the host.
+ *   dev_counts   uint32 [B,num_classes]      (zeroed by this call)
+ *   dev_row_min  int32  [B,num_classes,H]    W  when the row has no pixel of the class
+ *   dev_row_max  int32  [B,num_classes,H]    -1 when the row has no pixel of the class
+ * Asynchronous on `stream`. */
+int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int h, int w, uint32_t* dev_counts,
+                      int32_t* dev_row_min, int32_t* dev_row_max, void* stream);
+
 /* Bytes of device memory held by the engine (workspace + packed weights). */
 size_t unetpp_workspace_bytes(const unetpp_engine* e);
 

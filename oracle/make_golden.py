@@ -55,12 +55,13 @@ def _import_rule_scripts():
     strict = importlib.import_module("infer_video_strict")
     fixed = importlib.import_module("infer_video_fixed")
     robust = importlib.import_module("infer_video_robust")
-    return best, strict, fixed, robust
+    geom = importlib.import_module("src.utils.geometry_enhanced")
+    return best, strict, fixed, robust, geom
 
 
 def rule_payload(mods, logits):
     """cable/tape masks of every rule family, with the reference's default parameters, per frame."""
-    best, strict, fixed, robust = mods
+    best, strict, fixed, robust, geom = mods
     out = {}
     names = (("thr", lambda p: best.thresholded_argmax(p)), ("thr_strict", lambda p: strict.thresholded_argmax_strict(p)),
              ("bgcheck", lambda p: fixed.strict_threshold_with_bg_check(p)), ("excl", lambda p: robust.exclusive_threshold(p)),
@@ -77,6 +78,10 @@ def rule_payload(mods, logits):
         out[f"rule_{tag}_cable"] = np.stack(cs).astype(np.uint8)
         out[f"rule_{tag}_tape"] = np.stack(ts).astype(np.uint8)
     out["probs_hwc"] = np.stack(probs_all).astype(np.float32)
+    # per-row widths of the plain argmax masks by the reference's own _compute_width_per_row (no smoothing: cv2)
+    pred = np.argmax(np.stack(probs_all), axis=-1)
+    out["rowwidth_cable"] = np.stack([geom._compute_width_per_row((pred[i] == 1).astype(np.uint8), smooth=False) for i in range(pred.shape[0])])
+    out["rowwidth_tape"] = np.stack([geom._compute_width_per_row((pred[i] == 2).astype(np.uint8), smooth=False) for i in range(pred.shape[0])])
     return out
 
 

@@ -208,6 +208,26 @@ def exclusive_threshold_np(probs, t_cable=0.55, t_tape=0.60, bg_margin=0.20, ct_
     return cable.astype(np.uint8), tape.astype(np.uint8)
 
 
+def width_per_row_np(mask):
+    """_compute_width_per_row(mask, smooth=False) of src/utils/geometry_enhanced.py:45-74: per row,
+    xs.max() - xs.min() + 1 over the non-zero columns, 0 for an empty row (float32)."""
+    H, W = mask.shape
+    widths = np.zeros(H, dtype=np.float32)
+    for y in range(H):
+        xs = np.where(mask[y] > 0)[0]
+        if xs.size > 0:
+            widths[y] = float(xs.max() - xs.min() + 1)
+    return widths
+
+
+def mask_stats_np(pred, num_classes):
+    """counts[b,c] = np.sum(pred[b]==c) (infer_two_stage_burr.py:333-334) and widths[b,c,:] as above."""
+    B = pred.shape[0]
+    counts = np.stack([np.bincount(pred[b].ravel(), minlength=num_classes)[:num_classes] for b in range(B)]).astype(np.int64)
+    widths = np.stack([np.stack([width_per_row_np((pred[b] == c).astype(np.uint8)) for c in range(num_classes)]) for b in range(B)])
+    return counts, widths
+
+
 RULES = {"thresholded_argmax": thresholded_argmax_np, "strict_bg_check": strict_threshold_with_bg_check_np,
          "exclusive": exclusive_threshold_np}
 

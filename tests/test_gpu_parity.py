@@ -264,3 +264,29 @@ def test_probabilities_and_class_rules(tag, torch_cuda, syn, oracle):
         assert not (cable & tape).any()
     with pytest.raises(ValueError):
         model.segment_thresholded(x, rule="nope")
+
+
+def test_mask_statistics_on_device(torch_cuda, syn, oracle):
+    """class counts and per-row widths of the device mask equal the oracle's (and the
+    reference function's golden widths) exactly — integer work, bit-exact."""
+    torch = torch_cuda
+    g = load_golden("s_c3_128x96")
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    frames = syn.make_frames_u8(B, H, W, str(g["kind"]), int(g["fseed"]))
+    model, _ = make_model(3, True, int(g["wseed"]), "exact", syn, B, (H, W))
+    mask = model.segment(torch.from_numpy(frames).cuda())
+    counts, widths = model.mask_stats(mask)
+    torch.cuda.synchronize()
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    ref_counts, ref_widths = oracle.mask_stats_np(g["mask"], 3)
+    assert np.array_equal(counts.cpu().numpy(), ref_counts)
+    assert np.array_equal(widths.cpu().numpy(), ref_widths)
+    assert np.array_equal(widths.cpu().numpy()[:, 1], g["rowwidth_cable"])
+    # ragged: random masks with empty rows, classes beyond num_classes ignored, W not a multiple of 256
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 5, (3, 37, 300), dtype=np.uint8)
+    m[1, 5] = 0; m[2, :, :7] = 2
+    c2, w2 = model.mask_stats(torch.from_numpy(m).cuda())
+    rc, rw = oracle.mask_stats_np(np.where(m < 3, m, 255).astype(np.uint8), 3)
+    rc = np.stack([[(m[b] == c).sum() for c in range(3)] for b in range(3)])
+    assert np.array_equal(c2.cpu().numpy(), rc) and np.array_equal(w2.cpu().numpy(), rw)

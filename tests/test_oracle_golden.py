@@ -115,3 +115,14 @@ def test_probability_rules_match_reference_scripts(tag, oracle):
         assert np.array_equal(tape, g[f"rule_{key}_tape"]), key
         assert not (cable & tape).any()
     np.testing.assert_allclose(probs, g["probs_hwc"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["s_c3_64x64", "s_c3_128x96"])
+def test_mask_statistics_match_reference_function(tag, oracle):
+    """Per-row widths pinned by the reference's own _compute_width_per_row (src/utils/geometry_enhanced.py,
+    imported with a cv2 stub, smooth=False) on the golden argmax masks."""
+    g = load_golden(tag)
+    counts, widths = oracle.mask_stats_np(g["mask"], 3)
+    np.testing.assert_array_equal(widths[:, 1], g["rowwidth_cable"])
+    np.testing.assert_array_equal(widths[:, 2], g["rowwidth_tape"])
+    assert counts.sum() == g["mask"].size and counts[:, 1].sum() == int(g["mask_cable"].sum())

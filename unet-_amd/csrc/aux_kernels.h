@@ -247,6 +247,40 @@ __global__ void head_argmax_kernel(const half_t* __restrict__ x, const float* __
   if (tape) tape[i] = besti == 2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-frame mask statistics so that the uint8 mask need not leave the GPU when the
+// host only wants counts and widths:
+//   counts[b][c]         = number of pixels of class c            (np.sum(mask_cable), infer_two_stage_burr.py:333-334;
+//                                                                  cable_coverage = sum / (H*W), geometry_enhanced.py:151-152)
+//   row_min/max[b][c][y] = first / last column of class c in row y (W / -1 when the row has none): the per-row
+//                          width xs.max() - xs.min() + 1 of _compute_width_per_row (geometry_enhanced.py:45-74)
+// grid = (H, B), one workgroup per mask row; classes >= C are ignored.
+__global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restrict__ mask, int C, int H, int W,
+                                                         unsigned* __restrict__ counts, int* __restrict__ row_min,
+                                                         int* __restrict__ row_max) {
+  __shared__ int s_min[HEAD_MAX_CLASSES], s_max[HEAD_MAX_CLASSES];
+  __shared__ unsigned s_cnt[HEAD_MAX_CLASSES];
+  const int y = blockIdx.x, b = blockIdx.y;
+  if ((int)threadIdx.x < C) { s_min[threadIdx.x] = W; s_max[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
+  __syncthreads();
+  const uint8_t* row = mask + ((size_t)b * H + y) * W;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    const int c = row[x];
+    if (c < C) {
+      atomicMin(&s_min[c], x);
+      atomicMax(&s_max[c], x);
+      atomicAdd(&s_cnt[c], 1u);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    row_min[((size_t)b * C + c) * H + y] = s_min[c];
+    row_max[((size_t)b * C + c) * H + y] = s_max[c];
+    if (s_cnt[c]) atomicAdd(&counts[(size_t)b * C + c], s_cnt[c]);
+  }
+}
+
 // debug: channel-blocked fp16 -> float32 NCHW
 template <int P>
 __global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, int H, int W, float* __restrict__ out) {

@@ -551,6 +551,21 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
   return Lx.rc;
 }
 
+int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int h, int w, uint32_t* dev_counts,
+                      int32_t* dev_row_min, int32_t* dev_row_max, void* stream) {
+  if (!e) return UNETPP_E_INVALID;
+  if (!dev_mask || !dev_counts || !dev_row_min || !dev_row_max) return fail(e, UNETPP_E_INVALID, "null argument");
+  if (batch < 1 || h < 1 || w < 1) return fail(e, UNETPP_E_INVALID, "bad shape %dx%dx%d", batch, h, w);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int C = e->cfg.num_classes;
+  HIP_TRY(e, hipMemsetAsync(dev_counts, 0, (size_t)batch * C * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(mask_stats_kernel, dim3((unsigned)h, (unsigned)batch), dim3(256), 0, s, dev_mask, C, h, w,
+                     (unsigned*)dev_counts, (int*)dev_row_min, (int*)dev_row_max);
+  HIP_TRY(e, hipGetLastError());
+  return UNETPP_OK;
+}
+
 // ---- profiling -------------------------------------------------------------------------------------
 int unetpp_profile_enable(unetpp_engine* e, int on) {
   if (!e) return UNETPP_E_INVALID;

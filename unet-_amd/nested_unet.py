@@ -219,6 +219,31 @@ class NestedUNet:
         r = self._run(x, False, False, True, return_probs, rule, (t_cable, t_tape, bg_margin, ct_margin))
         return (r[2], r[3], r[4]) if return_probs else (r[2], r[3])
 
+    def mask_stats(self, mask):
+        """Device-side reductions of a uint8 class-index mask [B,H,W] (e.g. from segment()):
+        returns (counts int64 [B,C], widths float32 [B,C,H]) where counts[b,c] = np.sum(mask[b]==c)
+        (infer_two_stage_burr.py:333-334) and widths[b,c,y] = xs.max()-xs.min()+1 over the columns of class c
+        in row y, 0 for empty rows (_compute_width_per_row, src/utils/geometry_enhanced.py:45-74, before its
+        optional smoothing).  Only B*C*(2H+1) integers cross to the caller instead of the mask."""
+        import torch
+        if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dtype == torch.uint8 and mask.dim() == 3):
+            raise RuntimeError("mask must be a uint8 CUDA tensor [B,H,W]")
+        if self._handle is None:
+            raise RuntimeError("engine not initialised: run a forward first")
+        mask = mask.contiguous()
+        b, h, w = mask.shape
+        c = self.num_classes
+        counts = torch.empty((b, c), dtype=torch.int32, device=mask.device)
+        rmin = torch.empty((b, c, h), dtype=torch.int32, device=mask.device)
+        rmax = torch.empty((b, c, h), dtype=torch.int32, device=mask.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        rc = _lib.load().unetpp_mask_stats(self._handle, p(mask), b, h, w, p(counts), p(rmin), p(rmax),
+                                           ctypes.c_void_p(torch.cuda.current_stream(mask.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        widths = torch.where(rmax >= 0, (rmax - rmin + 1), torch.zeros_like(rmax)).to(torch.float32)
+        return counts.to(torch.int64), widths
+
     def predict_proba(self, x):
         """softmax(model(x), dim=1) as float32 [B,C,H,W] on the device (one fused pass)."""
         return self._run(x, False, False, False, True)[4]
