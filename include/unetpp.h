@@ -39,6 +39,13 @@ enum {
  *   FAST   plain fp16 operands, fp32 accumulate: single MFMA per product.                      */
 enum { UNETPP_PREC_EXACT = 0, UNETPP_PREC_FAST = 1 };
 
+/* network architecture of an engine */
+enum {
+  UNETPP_ARCH_NESTED = 0,    /* NestedUNet, src/models/unetpp.py:28-135 (the north-star path) */
+  UNETPP_ARCH_SIMPLE = 1     /* SimpleUNet, src/models/simple_unet.py:20-128: plain 4-level U-Net,
+                                no BatchNorm, ConvTranspose2d(k=2,s=2) upsampling, cat([up, skip]); H, W multiples of 8 */
+};
+
 /* input formats accepted by unetpp_forward */
 enum {
   UNETPP_IN_F32_NCHW = 0,    /* float32 [B,3,H,W] RGB in [0,1]: the tensor model(img_tensor) receives,
@@ -60,6 +67,7 @@ typedef struct unetpp_config {
   int streams;       /* passes in flight at once (1..4): each gets its own activation area and an internal
                         HIP stream, forked from / joined to the caller's stream with events, so HBM-bound
                         and MFMA-bound kernels of different passes overlap; 0 or 1 = serial */
+  int arch;          /* UNETPP_ARCH_* */
 } unetpp_config;
 
 /* NestedUNet.__init__ + .to(device) (src/models/unetpp.py:40-91, infer_two_stage_burr.py:214):
@@ -75,11 +83,16 @@ const char* unetpp_last_error(const unetpp_engine* e);
 const char* unetpp_version(void);
 
 /* Size in bytes of the canonical weight blob for a (num_classes, in_channels) network:
- * 32-byte header {magic 'UNPP', version, num_classes, in_channels, n_convs, 0,0,0} followed, for
+ * 32-byte header {magic 'UNPP', version, num_classes, in_channels, n_layers, arch, 0,0} followed, for
  * each of the 18 3x3 convs in forward order (conv0_0.conv1, conv0_0.conv2, conv1_0.conv1, ...,
  * conv0_4.conv2) and then the 1x1 head, by the BN-folded fp32 weight in OIHW order and the
  * folded fp32 bias.  The host side (unet-_amd/packing.py) builds it from a state_dict. */
 size_t unetpp_weights_blob_bytes(int num_classes, int in_channels);
+
+/* Same for any architecture (header word 5 = arch).  SimpleUNet: the 8 encoder convs enc1.0 ... enc4.2, then
+ * up3, up2, up1 (ConvTranspose2d weight in its native [Cin][Cout][2][2] order + bias), then dec3.0 ... dec1.2,
+ * then the 1x1 head — the module's definition order (simple_unet.py:30-92); no BatchNorm to fold. */
+size_t unetpp_weights_blob_bytes_arch(int arch, int num_classes, int in_channels);
 
 /* model.load_state_dict(checkpoint['model'], strict=True) (infer_two_stage_burr.py:215-216):
  * takes the canonical blob from host memory, uploads it and repacks it on the device into the

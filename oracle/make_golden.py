@@ -171,12 +171,50 @@ def main():
                           f"class_hist={np.bincount(pred.ravel(), minlength=C).tolist()} near_ties(<1e-3)={len(tie_margin)} "
                           f"min_margin={m.min():.3e}")
 
+    # ---- SimpleUNet: the reference class on our synthetic state_dict
+    from src.models.simple_unet import SimpleUNet
+    simple_cases = [("su_c7_32x48", 7, 0, 1, 32, 48, "smooth", 31, True), ("su_c7_256x256", 7, 0, 1, 256, 256, "smooth", 32, False),
+                    ("su_c3_64x40", 3, 1, 1, 64, 40, "uniform", 33, False)]
+    for tag, C, wseed, B, H, W, kind, fseed, inter in simple_cases:
+        sd_np = syn.make_simple_state_dict(C, 3, wseed)
+        model = SimpleUNet(num_classes=C, num_channels=3)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+        model.eval()
+        frames = syn.make_frames_u8(B, H, W, kind, fseed)
+        x = torch.from_numpy(syn.frames_to_chw_f32(frames))
+        got = {}
+        hooks = []
+        if inter:
+            for nm in ("enc1", "enc2", "enc3", "enc4", "dec3", "dec2", "dec1"):
+                hooks.append(getattr(model, nm)[3].register_forward_hook(
+                    lambda m, i, o, t=nm: got.__setitem__(t, o.detach().clone().numpy())))
+        with torch.no_grad():
+            out = model(x)
+            probs = torch.softmax(out, dim=1).numpy()           # infer_video_simple.py:96
+        for hk in hooks:
+            hk.remove()
+        logits = out.numpy()
+        payload = dict(num_classes=C, wseed=wseed, B=B, H=H, W=W, kind=kind, fseed=fseed, frames_sha=sha(frames))
+        if H * W <= 64 * 64:
+            payload.update(logits=logits.astype(np.float32), probs=probs.astype(np.float32))
+        else:
+            m = margin_of(logits)
+            payload.update(logits_sub4=logits[:, :, ::4, ::4].astype(np.float32), probs_sub4=probs[:, :, ::4, ::4].astype(np.float32),
+                           tie_idx=np.argwhere(m < 1e-3).astype(np.int32))
+        payload["mask"] = np.argmax(probs, axis=1).astype(np.uint8)
+        for k, v in got.items():
+            payload["t_" + k] = v.astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **payload)
+        meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] class_hist={np.bincount(payload['mask'].ravel(), minlength=C).tolist()}")
+    simple_manifest = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in SimpleUNet(7, 3).state_dict().items()]
+
     # ---- state_dict manifests (loader tests) for the two constructor variants the callers use
     manifest = {}
     for C, ds in ((3, True), (7, False)):
         model = NestedUNet(num_classes=C, input_channels=3, deep_supervision=ds)
         manifest[f"c{C}_ds{int(ds)}"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")]
                                          for k, v in model.state_dict().items()]
+    manifest["simple_c7"] = simple_manifest
     import json
     with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0)

@@ -11,6 +11,8 @@ What is restated (citations are /root/reference paths):
   * torch.cat([skip, up],1)     src/models/unetpp.py:112-116  (skip channels first)
   * final 1x1 conv              src/models/unetpp.py:85,119
   * softmax -> argmax -> uint8, class masks   infer_two_stage_burr.py:299-304
+  *  SimpleUNet.forward     src/models/simple_unet.py:94-128 (ConvTranspose2d k2 s2, cat([up, skip]))
+  *  per-row mask widths     src/utils/geometry_enhanced.py:45-74
   *  softmax probabilities + thresholded / strict / exclusive class rules
                                 infer_video_3class_best.py:50-83, infer_video_strict.py:36-63,
                                 infer_video_fixed.py:35-83, infer_video_robust.py:64-99
@@ -164,6 +166,81 @@ def top2_margin(logits: np.ndarray) -> np.ndarray:
     """Per-pixel gap between the largest and second-largest logit (for margin-aware flip accounting)."""
     s = np.sort(logits, axis=1)
     return (s[:, -1] - s[:, -2]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- SimpleUNet (SURVEY §8(f) row 3)
+def conv_transpose2x2_np(x, w, b):
+    """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (src/models/simple_unet.py:62-64):
+    out[n,co,2y+dy,2x+dx] = b[co] + sum_ci x[n,ci,y,x] * w[ci,co,dy,dx]   (weight layout [Cin,Cout,2,2])."""
+    B, Ci, H, W = x.shape
+    Co = w.shape[1]
+    out = np.empty((B, Co, 2 * H, 2 * W), dtype=x.dtype)
+    for dy in range(2):
+        for dx in range(2):
+            out[:, :, dy::2, dx::2] = np.einsum("bchw,co->bohw", x, w[:, :, dy, dx].astype(x.dtype), optimize=True)
+    return out + b.astype(x.dtype)[None, :, None, None]
+
+
+def simple_unet_numpy_forward(sd: dict, x: np.ndarray, dtype=np.float32, return_intermediates: bool = False):
+    """SimpleUNet.forward (src/models/simple_unet.py:94-128): four Conv-ReLU-Conv-ReLU encoders with 2x2
+    max-pools, three ConvTranspose2d upsamplers, cat([up, skip]) decoders, 1x1 head."""
+    if x.shape[2] % 8 or x.shape[3] % 8:
+        raise RuntimeError("Sizes of tensors must match: H and W must be multiples of 8")
+    x = x.astype(dtype)
+
+    def cr2(x, name):
+        for j in (0, 2):
+            x = relu_np(conv3x3_np(x, sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"]))
+        return x
+
+    t = {}
+    t["enc1"] = cr2(x, "enc1")
+    t["enc2"] = cr2(maxpool2x2_np(t["enc1"]), "enc2")
+    t["enc3"] = cr2(maxpool2x2_np(t["enc2"]), "enc3")
+    t["enc4"] = cr2(maxpool2x2_np(t["enc3"]), "enc4")
+    up3 = conv_transpose2x2_np(t["enc4"], sd["up3.weight"], sd["up3.bias"])
+    t["dec3"] = cr2(np.concatenate([up3, t["enc3"]], 1), "dec3")
+    up2 = conv_transpose2x2_np(t["dec3"], sd["up2.weight"], sd["up2.bias"])
+    t["dec2"] = cr2(np.concatenate([up2, t["enc2"]], 1), "dec2")
+    up1 = conv_transpose2x2_np(t["dec2"], sd["up1.weight"], sd["up1.bias"])
+    t["dec1"] = cr2(np.concatenate([up1, t["enc1"]], 1), "dec1")
+    logits = conv1x1_np(t["dec1"], sd["final.weight"], sd["final.bias"])
+    if return_intermediates:
+        return logits, t
+    return logits
+
+
+def simple_unet_torch_forward(sd: dict, x, return_intermediates: bool = False):
+    """The same graph through torch.nn.functional CPU ops (what the reference dispatches to)."""
+    import torch
+    import torch.nn.functional as F
+
+    def T(a):
+        return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+
+    x = T(x).float()
+    if x.shape[2] % 8 or x.shape[3] % 8:
+        raise RuntimeError("Sizes of tensors must match: H and W must be multiples of 8")
+
+    def cr2(x, name):
+        for j in (0, 2):
+            x = F.relu(F.conv2d(x, T(sd[f"{name}.{j}.weight"]), T(sd[f"{name}.{j}.bias"]), padding=1))
+        return x
+
+    with torch.no_grad():
+        t = {}
+        t["enc1"] = cr2(x, "enc1")
+        t["enc2"] = cr2(F.max_pool2d(t["enc1"], 2, 2), "enc2")
+        t["enc3"] = cr2(F.max_pool2d(t["enc2"], 2, 2), "enc3")
+        t["enc4"] = cr2(F.max_pool2d(t["enc3"], 2, 2), "enc4")
+        prev = t["enc4"]
+        for l in (3, 2, 1):
+            up = F.conv_transpose2d(prev, T(sd[f"up{l}.weight"]), T(sd[f"up{l}.bias"]), stride=2)
+            prev = t[f"dec{l}"] = cr2(torch.cat([up, t[f"enc{l}"]], 1), f"dec{l}")
+        logits = F.conv2d(prev, T(sd["final.weight"]), T(sd["final.bias"]))
+    if return_intermediates:
+        return logits.numpy(), {k: v.numpy() for k, v in t.items()}
+    return logits.numpy()
 
 
 # ----------------------------------------------------------------------------- probability rules (SURVEY §8(f) row 1)

@@ -290,3 +290,58 @@ def test_mask_statistics_on_device(torch_cuda, syn, oracle):
     rc, rw = oracle.mask_stats_np(np.where(m < 3, m, 255).astype(np.uint8), 3)
     rc = np.stack([[(m[b] == c).sum() for c in range(3)] for b in range(3)])
     assert np.array_equal(c2.cpu().numpy(), rc) and np.array_equal(w2.cpu().numpy(), rw)
+
+
+@pytest.mark.parametrize("tag", ["su_c7_32x48", "su_c3_64x40", "su_c7_256x256"])
+def test_simple_unet_matches_golden(tag, torch_cuda, syn, oracle):
+    """SimpleUNet (conv3x3 + ReLU, pool, ConvTranspose2d k2 s2, cat([up, skip]), 1x1 head)
+    against the reference class's outputs; 7-class 256x256 is the shape infer_video_simple.py:88 runs."""
+    torch = torch_cuda
+    from unet_amd.nested_unet import SimpleUNet
+    g = load_golden(tag)
+    B, H, W, C = int(g["B"]), int(g["H"]), int(g["W"]), int(g["num_classes"])
+    frames = syn.make_frames_u8(B, H, W, str(g["kind"]), int(g["fseed"]))
+    sd = syn.make_simple_state_dict(C, 3, int(g["wseed"]))
+    model = SimpleUNet(num_classes=C, num_channels=3, max_batch=B, max_hw=(H, W)).to("cuda:0")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    logits = model(x)
+    probs = model.predict_proba(x)
+    mask = model.segment(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    lg, pr, mk = logits.cpu().numpy(), probs.cpu().numpy(), mask.cpu().numpy()
+    if "logits" in g.files:
+        err = float(np.abs(lg - g["logits"]).max()); perr = float(np.abs(pr - g["probs"]).max())
+        margin = oracle.top2_margin(g["logits"])
+        assert not ((mk != g["mask"]) & (margin > 1e-4)).any()
+        for k in [f for f in g.files if f.startswith("t_")]:
+            got = model.debug_activation(k[2:], B, H, W)
+            np.testing.assert_allclose(got, g[k], rtol=0, atol=3e-5, err_msg=k)
+    else:
+        err = float(np.abs(lg[:, :, ::4, ::4] - g["logits_sub4"]).max()); perr = float(np.abs(pr[:, :, ::4, ::4] - g["probs_sub4"]).max())
+        ties = {tuple(t) for t in g["tie_idx"].tolist()}
+        assert all(tuple(d) in ties for d in np.argwhere(mk != g["mask"]).tolist())
+    print(f"{tag}: max|dlogit|={err:.3e} max|dprob|={perr:.3e} mask diffs={int((mk != g['mask']).sum())}")
+    assert err < 5e-5 and perr < 1e-5
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        model(torch.zeros(1, 3, 36, 32, device="cuda"))
+
+
+def test_simple_unet_fast_and_batch_invariance(torch_cuda, syn, oracle):
+    torch = torch_cuda
+    from unet_amd.nested_unet import SimpleUNet
+    sd = syn.make_simple_state_dict(7, 3, 0)
+    frames = syn.make_frames_u8(3, 64, 96, "smooth", 41)
+    x = syn.frames_to_chw_f32(frames)
+    ref = oracle.simple_unet_torch_forward(sd, x)
+    xt = torch.from_numpy(x).cuda()
+    for prec, tol in (("exact", 5e-5), ("fast", 6e-2)):
+        m = SimpleUNet(7, precision=prec, max_batch=3, max_hw=(64, 96)).to("cuda:0")
+        m.load_state_dict(sd)
+        a = m(xt); b = m(xt[1:2])
+        torch.cuda.synchronize()
+        assert torch.equal(a[1:2], b)
+        err = float(np.abs(a.cpu().numpy() - ref).max())
+        print(f"simple {prec}: max|dlogit|={err:.3e}")
+        assert err < tol

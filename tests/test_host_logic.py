@@ -31,7 +31,7 @@ def test_blob_size_matches_abi(syn):
         blob = packing.build_blob(sd, C)
         assert blob.nbytes == lib.unetpp_weights_blob_bytes(C, 3)
         hdr = blob[:32].view(np.uint32)
-        assert hdr[0] == packing.BLOB_MAGIC and hdr[2] == C and hdr[4] == 19
+        assert hdr[0] == packing.BLOB_MAGIC and hdr[2] == C and hdr[4] == 19 and hdr[5] == 0
     # 7,846,723 folded conv weights+biases for the 3-class net
     assert (lib.unetpp_weights_blob_bytes(3, 3) - 32) // 4 == 7846723
 
@@ -42,7 +42,7 @@ def test_create_without_gpu_fails_loudly():
         pytest.skip("GPU present")
     from unet_amd import _lib
     lib = _lib.load()
-    cfg = _lib.Config(3, 3, 1, 32, 32, 0, 0, 0, 1)
+    cfg = _lib.Config(3, 3, 1, 32, 32, 0, 0, 0, 1, 0)
     h = ctypes.c_void_p()
     rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc != 0 and not h.value

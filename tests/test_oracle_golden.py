@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/unetpp_oracle.py) to the reference: every committed golden vector was
 produced by the reference NestedUNet itself (oracle/make_golden.py).  CPU only."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -126,3 +127,47 @@ def test_mask_statistics_match_reference_function(tag, oracle):
     np.testing.assert_array_equal(widths[:, 1], g["rowwidth_cable"])
     np.testing.assert_array_equal(widths[:, 2], g["rowwidth_tape"])
     assert counts.sum() == g["mask"].size and counts[:, 1].sum() == int(g["mask_cable"].sum())
+
+
+SIMPLE = ["su_c7_32x48", "su_c3_64x40", "su_c7_256x256"]
+
+
+@pytest.mark.parametrize("tag", SIMPLE)
+def test_simple_unet_restatements_match_reference(tag, oracle, syn):
+    """SimpleUNet oracle (torch and NumPy) pinned by the reference class's own outputs."""
+    g = load_golden(tag)
+    B, H, W, C = int(g["B"]), int(g["H"]), int(g["W"]), int(g["num_classes"])
+    frames = syn.make_frames_u8(B, H, W, str(g["kind"]), int(g["fseed"]))
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha"])
+    sd = syn.make_simple_state_dict(C, 3, int(g["wseed"]))
+    x = syn.frames_to_chw_f32(frames)
+    lt, tt = oracle.simple_unet_torch_forward(sd, x, return_intermediates=True)
+    if "logits" in g.files:
+        np.testing.assert_allclose(lt, g["logits"], rtol=0, atol=5e-6)
+        ln, tn = oracle.simple_unet_numpy_forward(sd, x, return_intermediates=True)
+        np.testing.assert_allclose(ln, g["logits"], rtol=0, atol=5e-5)
+        for k in [f for f in g.files if f.startswith("t_")]:
+            np.testing.assert_allclose(tt[k[2:]], g[k], rtol=0, atol=5e-6, err_msg=k)
+            np.testing.assert_allclose(tn[k[2:]], g[k], rtol=0, atol=5e-5, err_msg=k)
+    else:
+        np.testing.assert_allclose(lt[:, :, ::4, ::4], g["logits_sub4"], rtol=0, atol=1e-5)
+    probs = oracle.softmax_np(lt, axis=1)
+    ref_p = g["probs"] if "probs" in g.files else None
+    if ref_p is not None:
+        np.testing.assert_allclose(probs, ref_p, rtol=0, atol=2e-6)
+    differs = np.argwhere(np.argmax(probs, axis=1) != g["mask"])
+    assert len(differs) <= 2
+
+
+def test_simple_unet_manifest_and_blob(syn):
+    import json
+    from conftest import ROOT
+    from unet_amd import _lib, packing
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))["simple_c7"]
+    assert [[k, list(s), d] for k, s, d in syn.simple_unet_manifest(7, 3)] == man
+    sd = syn.make_simple_state_dict(7, 3, 0)
+    blob = packing.build_simple_blob(sd, 7)
+    assert blob.nbytes == _lib.load().unetpp_weights_blob_bytes_arch(1, 7, 3)
+    assert blob[:32].view(np.uint32)[5] == 1
+    with pytest.raises(RuntimeError, match="Missing key"):
+        bad = dict(sd); bad.pop("up2.bias"); packing.check_simple_state_dict(bad, 7)

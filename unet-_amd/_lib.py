@@ -12,24 +12,26 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunetpp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["unetpp_abi.hip"]
-HEADERS = ["conv3x3_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include", "unetpp.h")]
+HEADERS = ["conv3x3_mfma.h", "convt2x2_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include", "unetpp.h")]
 
 # every symbol include/unetpp.h declares
 ABI_SYMBOLS = [
     "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
+    "unetpp_weights_blob_bytes_arch",
     "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_forward_ex", "unetpp_mask_stats", "unetpp_workspace_bytes",
     "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
     "unetpp_profile_work", "unetpp_debug_read", "unetpp_debug_keep_intermediates",
 ]
 
 PREC_EXACT, PREC_FAST = 0, 1
+ARCH_NESTED, ARCH_SIMPLE = 0, 1
 IN_F32_NCHW, IN_U8_NHWC_BGR = 0, 1
 
 
 class Config(ctypes.Structure):
     _fields_ = [("num_classes", ctypes.c_int), ("in_channels", ctypes.c_int), ("max_batch", ctypes.c_int),
                 ("max_h", ctypes.c_int), ("max_w", ctypes.c_int), ("precision", ctypes.c_int),
-                ("device", ctypes.c_int), ("micro_batch", ctypes.c_int), ("streams", ctypes.c_int)]
+                ("device", ctypes.c_int), ("micro_batch", ctypes.c_int), ("streams", ctypes.c_int), ("arch", ctypes.c_int)]
 
 
 RULES = {"argmax": 0, "thresholded_argmax": 1, "strict_bg_check": 2, "exclusive": 3}
@@ -81,6 +83,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_last_error.argtypes = [vp]; lib.unetpp_last_error.restype = ctypes.c_char_p
     lib.unetpp_version.argtypes = []; lib.unetpp_version.restype = ctypes.c_char_p
     lib.unetpp_weights_blob_bytes.argtypes = [ci, ci]; lib.unetpp_weights_blob_bytes.restype = cs
+    lib.unetpp_weights_blob_bytes_arch.argtypes = [ci, ci, ci]; lib.unetpp_weights_blob_bytes_arch.restype = cs
     lib.unetpp_load_weights.argtypes = [vp, vp, cs]; lib.unetpp_load_weights.restype = ci
     lib.unetpp_load_weights_device.argtypes = [vp, vp, cs, vp]; lib.unetpp_load_weights_device.restype = ci
     lib.unetpp_forward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]; lib.unetpp_forward.restype = ci

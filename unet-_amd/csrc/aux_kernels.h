@@ -201,50 +201,77 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// self.final = Conv2d(32, C, 1) (unetpp.py:85,119) in fp32, then the frame-loop tail
-// softmax -> argmax -> uint8, (pred==1), (pred==2) (infer_two_stage_burr.py:299-304).  softmax is
-// monotone, so the class index is taken on the logits; ties resolve to the lowest index (np.argmax).
+// Stand-alone 1x1 head: self.final = Conv2d(Cx, C, 1) in fp32 (NestedUNet unetpp.py:85,119 with Cx = 32 —
+// only in debug mode, normally fused into conv0_4.conv2 — and SimpleUNet simple_unet.py:92,124 with
+// Cx = 64), then softmax probabilities, argmax (first maximal class, np.argmax) and the class rules
+// (apply_rule, conv3x3_mfma.h).  x is channel-blocked [N][Cx/16][H][W][P][16]; C <= HEAD_FUSED_MAX_CLASSES.
 template <int P>
-__global__ void head_argmax_kernel(const half_t* __restrict__ x, const float* __restrict__ w /*[C][32]*/,
-                                   const float* __restrict__ b, int C, int N, int H, int W,
-                                   float* __restrict__ logits, uint8_t* __restrict__ mask,
-                                   uint8_t* __restrict__ cable, uint8_t* __restrict__ tape) {
-  __shared__ float ws[HEAD_MAX_CLASSES * 32 + HEAD_MAX_CLASSES];
-  for (int i = threadIdx.x; i < C * 32; i += blockDim.x) ws[i] = w[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) ws[HEAD_MAX_CLASSES * 32 + i] = b[i];
+__global__ void head_generic_kernel(const half_t* __restrict__ x, int Cx, const float* __restrict__ w /*[C][Cx]*/,
+                                    const float* __restrict__ b, int C, int N, int H, int W,
+                                    float* __restrict__ logits, float* __restrict__ probs, uint8_t* __restrict__ mask,
+                                    uint8_t* __restrict__ cable, uint8_t* __restrict__ tape, int rule, float t_cable,
+                                    float t_tape, float bg_margin, float ct_margin) {
+  extern __shared__ float head_ws[];          // [C][Cx] weights then [C] biases
+  for (int i = threadIdx.x; i < C * Cx; i += blockDim.x) head_ws[i] = w[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) head_ws[C * Cx + i] = b[i];
   __syncthreads();
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t hw = (size_t)H * W, total = (size_t)N * hw;
-  if (i >= total) return;
-  size_t n = i / hw, p = i - n * hw;
-  float v[32];
+  const unsigned hw = (unsigned)(H * W);
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;     // pixel inside image blockIdx.y
+  const unsigned n = blockIdx.y;
+  if (p >= hw) return;
+  float lg[HEAD_FUSED_MAX_CLASSES];
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {            // x0_4 is channel-blocked: [N][2][H][W][P][16]
-    const half8* px = (const half8*)(x + (((n * 2 + blk) * hw + p) * P) * 16);
+  for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) lg[c] = (c < C) ? head_ws[C * Cx + c] : -INFINITY;
+  const int nblk = Cx >> 4;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const half8* px = (const half8*)(x + ((((size_t)n * nblk + blk) * hw + p) * P) * 16);
+    float v[16];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       half8 hi = px[g];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[blk * 16 + g * 8 + e] = (float)hi[e];
+      for (int e = 0; e < 8; ++e) v[g * 8 + e] = (float)hi[e];
       if (P == 2) {
         half8 lo = px[2 + g];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[blk * 16 + g * 8 + e] += (float)lo[e];
+        for (int e = 0; e < 8; ++e) v[g * 8 + e] += (float)lo[e];
       }
     }
-  }
-  float best = -INFINITY;
-  int besti = 0;
-  for (int c = 0; c < C; ++c) {
-    float s = ws[HEAD_MAX_CLASSES * 32 + c];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s = fmaf(v[e], ws[c * 32 + e], s);
-    if (logits) logits[(n * C + c) * hw + p] = s;
-    if (s > best) { best = s; besti = c; }
+    for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c)
+      if (c < C) {
+        float s = lg[c];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s = fmaf(v[e], head_ws[c * Cx + blk * 16 + e], s);
+        lg[c] = s;
+      }
   }
-  if (mask) mask[i] = (uint8_t)besti;
-  if (cable) cable[i] = besti == 1;
-  if (tape) tape[i] = besti == 2;
+  float best = lg[0];
+  int besti = 0;
+#pragma unroll
+  for (int c = 1; c < HEAD_FUSED_MAX_CLASSES; ++c)
+    if (lg[c] > best) { best = lg[c]; besti = c; }
+  bool is_cable = besti == 1, is_tape = besti == 2;
+  const size_t o = (size_t)n * hw + p;
+  if (probs || rule) {
+    float pe[HEAD_FUSED_MAX_CLASSES], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) { pe[c] = (c < C) ? expf(lg[c] - best) : 0.f; sum += pe[c]; }
+#pragma unroll
+    for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+      pe[c] = pe[c] / sum;
+      if (probs && c < C) probs[((size_t)n * C + c) * hw + p] = pe[c];
+    }
+    if (rule) apply_rule(rule, pe[0], pe[1], pe[2], t_cable, t_tape, bg_margin, ct_margin, is_cable, is_tape);
+  }
+  if (logits) {
+#pragma unroll
+    for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c)
+      if (c < C) logits[((size_t)n * C + c) * hw + p] = lg[c];
+  }
+  if (mask) mask[o] = (uint8_t)besti;
+  if (cable) cable[o] = is_cable;
+  if (tape) tape[o] = is_tape;
 }
 
 // ------------------------------------------------------------------------------------------------

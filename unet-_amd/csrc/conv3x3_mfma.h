@@ -137,6 +137,49 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                : "memory");
 }
 
+// Epilogue helper shared by the conv and transposed-conv kernels.  `v` = the 16 channel values of one pixel
+// held by this lane (channel (r & 3) + 8 * (r >> 2) + 4 * h of a 32-channel tile, h = lane >> 5).  Packs to
+// fp16 (hi/lo planes when P == 2), exchanges words with lane ^ 32 (v_permlane32_swap) so that every lane
+// owns 8 consecutive channels, and stores 16 bytes per plane and channel block.
+// dst -> plane 0 of the pixel in the tile's first channel block; blk_stride = halves between channel blocks.
+template <int P>
+__device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
+  unsigned wh[4][2], wl[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      const float v0 = fminf(v[4 * q + 2 * w2], 65504.0f), v1 = fminf(v[4 * q + 2 * w2 + 1], 65504.0f);
+      const half_t h0 = (half_t)v0, h1 = (half_t)v1;
+      half2v ph = {h0, h1};
+      wh[q][w2] = __builtin_bit_cast(unsigned, ph);
+      if (P == 2) {
+        half2v pl = {(half_t)(v0 - (float)h0), (half_t)(v1 - (float)h1)};
+        wl[q][w2] = __builtin_bit_cast(unsigned, pl);
+      }
+    }
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      auto r = __builtin_amdgcn_permlane32_swap(wh[2 * pi][w2], wh[2 * pi + 1][w2], false, false);
+      wh[2 * pi][w2] = r[0]; wh[2 * pi + 1][w2] = r[1];
+      if (P == 2) {
+        auto r2 = __builtin_amdgcn_permlane32_swap(wl[2 * pi][w2], wl[2 * pi + 1][w2], false, false);
+        wl[2 * pi][w2] = r2[0]; wl[2 * pi + 1][w2] = r2[1];
+      }
+    }
+    if (ok) {      // octet pi*16 + 8h of this 32-channel tile = channel block pi, halves 8h..8h+7
+      u32x4 o = {wh[2 * pi][0], wh[2 * pi][1], wh[2 * pi + 1][0], wh[2 * pi + 1][1]};
+      *(u32x4*)(dst + pi * blk_stride + 8 * h) = o;
+      if (P == 2) {
+        u32x4 o2 = {wl[2 * pi][0], wl[2 * pi][1], wl[2 * pi + 1][0], wl[2 * pi + 1][1]};
+        *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = o2;
+      }
+    }
+  }
+}
+
 constexpr int HEAD_MAX_CLASSES = 16;
 constexpr int HEAD_FUSED_MAX_CLASSES = 8;   // the fused head keeps all logits in registers
 
@@ -374,43 +417,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       const int h = lane >> 5;
       const int gx = cur_x0 + (lane & 31);
       const int nbo = a.Cout >> 4;                       // channel blocks of the output tensor
-      // dst -> plane 0 of the pixel in channel block (j*32)/16; blk_stride = halves between channel blocks
-      auto pack_store = [&](const float (&v)[16], half_t* dst, size_t blk_stride, bool ok) {
-        unsigned wh[4][2], wl[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int w2 = 0; w2 < 2; ++w2) {
-            const float v0 = fminf(v[4 * q + 2 * w2], 65504.0f), v1 = fminf(v[4 * q + 2 * w2 + 1], 65504.0f);
-            const half_t h0 = (half_t)v0, h1 = (half_t)v1;
-            half2v ph = {h0, h1};
-            wh[q][w2] = __builtin_bit_cast(unsigned, ph);
-            if (P == 2) {
-              half2v pl = {(half_t)(v0 - (float)h0), (half_t)(v1 - (float)h1)};
-              wl[q][w2] = __builtin_bit_cast(unsigned, pl);
-            }
-          }
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-#pragma unroll
-          for (int w2 = 0; w2 < 2; ++w2) {
-            auto r = __builtin_amdgcn_permlane32_swap(wh[2 * pi][w2], wh[2 * pi + 1][w2], false, false);
-            wh[2 * pi][w2] = r[0]; wh[2 * pi + 1][w2] = r[1];
-            if (P == 2) {
-              auto r2 = __builtin_amdgcn_permlane32_swap(wl[2 * pi][w2], wl[2 * pi + 1][w2], false, false);
-              wl[2 * pi][w2] = r2[0]; wl[2 * pi + 1][w2] = r2[1];
-            }
-          }
-          if (ok) {      // octet pi*16 + 8h of this 32-channel tile = channel block pi, halves 8h..8h+7
-            u32x4 o = {wh[2 * pi][0], wh[2 * pi][1], wh[2 * pi + 1][0], wh[2 * pi + 1][1]};
-            *(u32x4*)(dst + pi * blk_stride + 8 * h) = o;
-            if (P == 2) {
-              u32x4 o2 = {wl[2 * pi][0], wl[2 * pi][1], wl[2 * pi + 1][0], wl[2 * pi + 1][1]};
-              *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = o2;
-            }
-          }
-        }
-      };
+      auto pack_store = [&](const float (&v)[16], half_t* dst, size_t blk_stride, bool ok) { pack_store_octets<P>(v, dst, blk_stride, ok, h); };
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int cbase = cur_ct * BN + j * 32;

@@ -1,0 +1,153 @@
+// convt2x2_mfma.h — nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (reference
+// src/models/simple_unet.py:62-64, used at :109,114,119) as an MFMA GEMM:
+//   out[n][co][2y+dy][2x+dx] = b[co] + sum_ci in[n][ci][y][x] * W[ci][co][dy][dx]
+// = a 1x1 convolution with 4*Cout "virtual channels" v = (dy*2+dx)*Cout + co followed by a pixel shuffle
+// that the epilogue does while storing.  It is ~4 % of SimpleUNet's FLOPs, so the kernel is deliberately
+// simple: no LDS, no barriers; every wave owns a 128-pixel x 64-virtual-channel tile (8 accumulators)
+// and streams its MFMA operands straight from global memory / L2 (12 x 1 KiB loads per 24 MFMAs).
+// Same operand conventions as conv3x3_mfma.h: weights are the A operand (virtual channel on the row),
+// pixels the B operand (pixel on the lane); EXACT mode (P = 2) issues lo*hi, hi*lo, hi*hi.
+#pragma once
+#include "conv3x3_mfma.h"
+
+namespace unetpp {
+
+struct ConvTArgs {
+  const half_t* in;      // [N][Cin/16][H][W][P][16]
+  const half_t* wpk;     // packed weights [v-tile (32)][Cin/16][P][64 lanes][8]: the A fragment of lane l
+  const float* scale;    // [Cout] 2^-k undoing the per-channel weight scaling
+  const float* bias;     // [Cout]
+  half_t* out;           // [N][Cout/16][2H][2W][P][16]
+  int N, H, W, Cin, Cout;
+};
+
+template <int P>
+__global__ __launch_bounds__(256) void convt2x2_kernel(ConvTArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int HW = a.H * a.W;
+  const int n = blockIdx.z;
+  const int pbase = (blockIdx.x * 4 + wave) * 128;           // first flattened pixel of this wave's tile
+  if (pbase >= HW) return;                                    // whole wave out of range (no barriers in this kernel)
+  const int vt0 = blockIdx.y * 2;                             // first 32-wide virtual-channel tile
+  const int K16 = a.Cin >> 4;
+  const int h = lane >> 5;
+
+  float16v acc[4][2];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][j][r] = 0.f;
+
+  int pix[4];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) pix[pt] = min(pbase + pt * 32 + (lane & 31), HW - 1);   // clamp: discarded at the store
+  const half_t* in_n = a.in + (size_t)n * a.Cin * HW * P;
+
+  for (int kk = 0; kk < K16; ++kk) {
+    half8 wh[2], wl[2], xh[4], xl[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* w = a.wpk + (((size_t)(vt0 + j) * K16 + kk) * P) * 512 + lane * 8;
+      wh[j] = *(const half8*)w;
+      if (P == 2) wl[j] = *(const half8*)(w + 512);
+    }
+    const half_t* blk = in_n + (size_t)kk * HW * (P * 16) + h * 8;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const half_t* x = blk + (size_t)pix[pt] * (P * 16);
+      xh[pt] = *(const half8*)x;
+      if (P == 2) xl[pt] = *(const half8*)(x + 16);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (P == 2) {
+          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[pt], acc[pt][j], 0, 0, 0);
+          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[pt], acc[pt][j], 0, 0, 0);
+        }
+        acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[pt], acc[pt][j], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: scale, bias (no activation), pixel shuffle, fp16 hi/lo packing, 16-byte stores
+  const int H2 = 2 * a.H, W2 = 2 * a.W;
+  const size_t oblk = (size_t)H2 * W2 * P * 16;                // halves per channel block of the output
+  const int nbo = a.Cout >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int vb = (vt0 + j) * 32;                             // a 32-wide tile never straddles a (dy,dx) group: 32 | Cout
+    const int q = vb / a.Cout, cbase = vb - q * a.Cout;
+    const int dy = q >> 1, dx = q & 1;
+    float sc[16], bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+      sc[r] = a.scale[co]; bi[r] = a.bias[co];
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int p = pbase + pt * 32 + (lane & 31);
+      const bool ok = p < HW;
+      const int pc = min(p, HW - 1);
+      const int y = pc / a.W, x = pc - y * a.W;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[pt][j][r] * sc[r] + bi[r];
+      half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * oblk + ((size_t)(2 * y + dy) * W2 + (2 * x + dx)) * (P * 16);
+      pack_store_octets<P>(v, dst, oblk, ok, h);
+    }
+  }
+}
+
+// per-output-channel weight scale for a ConvTranspose2d weight [Cin][Cout][2][2]
+__global__ void convt_scale_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ mult_out,
+                                   float* __restrict__ scale_out) {
+  const int co = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < Cin * 4; i += blockDim.x) m = fmaxf(m, fabsf(w[((size_t)(i >> 2) * Cout + co) * 4 + (i & 3)]));
+  __shared__ float red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int e = 0, k = 0;
+    const float mm = red[0];
+    if (mm > 0.f && mm < 3.0e38f) { frexpf(mm, &e); k = 14 - e; }
+    mult_out[co] = ldexpf(1.0f, k);
+    scale_out[co] = ldexpf(1.0f, -k);
+  }
+}
+
+// [Cin][Cout][2][2] fp32 -> [v-tile][Cin/16][P][64 lanes][8] fp16: lane l of the A fragment holds virtual channel
+// vt*32 + (l & 31), input channels kk*16 + 8*(l >> 5) + 0..7
+__global__ void convt_pack_kernel(const float* __restrict__ w, const float* __restrict__ mult, int Cin, int Cout, int P,
+                                  half_t* __restrict__ out, long long units) {
+  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  long long t = u;
+  const int lane = t % 64; t /= 64;
+  const int pl = t % P; t /= P;
+  const int K16 = Cin / 16;
+  const int kk = t % K16; t /= K16;
+  const int vt = (int)t;
+  const int v = vt * 32 + (lane & 31);
+  const int q = v / Cout, co = v - q * Cout;
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = kk * 16 + 8 * (lane >> 5) + e;
+    const float val = w[((size_t)ci * Cout + co) * 4 + q] * mult[co];
+    const half_t hi = (half_t)val;
+    r[e] = pl == 0 ? hi : (half_t)(val - (float)hi);
+  }
+  *(half8*)(out + u * 8) = r;
+}
+
+}  // namespace unetpp

@@ -1,10 +1,16 @@
-// unetpp_abi.hip — engine + C ABI (include/unetpp.h) of the MI355X-native UNet++ inference path.
-// Graph executed (reference src/models/unetpp.py:104-119, eval mode):
+// unetpp_abi.hip — engine + C ABI (include/unetpp.h) of the MI355X-native U-Net inference paths.
+//
+// arch 0, NestedUNet (reference src/models/unetpp.py:104-119, eval mode):
 //   x0_0 = CB(3,32)(x)            x1_0 = CB(32,64)(pool x0_0)     x2_0 = CB(64,128)(pool x1_0)
 //   x3_0 = CB(128,256)(pool x2_0) x4_0 = CB(256,512)(pool x3_0)
 //   x3_1 = CB(768,256)(cat[x3_0, up x4_0])   x2_2 = CB(384,128)(cat[x2_0, up x3_1])
 //   x1_3 = CB(192,64)(cat[x1_0, up x2_2])    x0_4 = CB(96,32)(cat[x0_0, up x1_3])
 //   out  = Conv1x1(32,C)(x0_4)  -> argmax / class masks (infer_two_stage_burr.py:299-304)
+// arch 1, SimpleUNet (reference src/models/simple_unet.py:94-128):
+//   enc1 = CR(3,64) CR(64,64)(x)        enc2 = CR CR(pool enc1) [128]   enc3 [256]   enc4 [512]
+//   dec3 = CR CR(cat[ConvT(512,256)(enc4), enc3])   dec2 = CR CR(cat[ConvT(256,128)(dec3), enc2])
+//   dec1 = CR CR(cat[ConvT(128,64)(dec2), enc1])    out = Conv1x1(64,C)(dec1)
+// Both are executed from one op list (convert, conv3x3, upsample, convT, head) built in unetpp_create.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,6 +24,7 @@
 #include "../../include/unetpp.h"
 #include "aux_kernels.h"
 #include "conv3x3_mfma.h"
+#include "convt2x2_mfma.h"
 
 using namespace unetpp;
 
@@ -28,9 +35,11 @@ thread_local std::string g_create_error;
 constexpr uint32_t BLOB_MAGIC = 0x50504e55u;  // 'UNPP'
 constexpr int BLOB_VERSION = 1;
 const int NB[5] = {32, 64, 128, 256, 512};    // nb_filter, reference unetpp.py:49
+const int SB[4] = {64, 128, 256, 512};        // SimpleUNet widths, simple_unet.py:32-57
 
 struct Tensor {
-  half_t* p = nullptr;
+  std::string name;
+  size_t off = 0;   // byte offset inside one activation slot
   int C = 0;
   int lvl = 0;
 };
@@ -40,7 +49,7 @@ struct ConvLayer {
   int cin_real = 0;   // channels the canonical weight has
   int cout = 0;
   int lvl = 0;
-  Tensor in, in2, out, pool;   // in2: second source of the virtual concat (C = 0 when unused)
+  int in = -1, in2 = -1, out = -1, pool = -1;   // tensor ids; in2: second source of the virtual concat
   bool do_pool = false;
   size_t w_off = 0, b_off = 0;  // float offsets inside the canonical blob payload
   int KC = 16, NW = 1, MW = 2, WAVES = 8;
@@ -48,6 +57,24 @@ struct ConvLayer {
   half_t* wpk = nullptr;
   float* scale = nullptr;
   float* mult = nullptr;
+};
+
+struct ConvTLayer {
+  std::string name;
+  int cin = 0, cout = 0, lvl = 0;   // lvl = level of the INPUT (the output is one level up)
+  int in = -1, out = -1;
+  size_t w_off = 0, b_off = 0;
+  half_t* wpk = nullptr;
+  float* scale = nullptr;
+  float* mult = nullptr;
+};
+
+enum OpKind { OP_CONVERT, OP_CONV, OP_UP, OP_CONVT, OP_HEAD };
+struct Op {
+  OpKind kind;
+  int idx = -1;            // conv / convT index, or (OP_UP) source tensor id
+  int out = -1;            // OP_UP: destination tensor id; OP_HEAD: input tensor id
+  bool fuse_head = false;  // OP_CONV: run the 1x1 head in this conv's epilogue when allowed
 };
 
 struct ProfRec {
@@ -69,9 +96,13 @@ struct unetpp_engine {
   float* blob = nullptr;  // canonical fp32 blob payload on device (weights + biases)
   size_t blob_floats = 0;
   bool weights_loaded = false;
-  std::vector<ConvLayer> convs;  // 18
-  Tensor in8, up[4];             // up[l]: bilinear x2 of the level l+1 node, at level l
-  Tensor x[5], xa[5], pooled[4], d[4], da[4];  // encoder x{l}_0, its conv1 temp, pooled; decoder nodes
+  std::vector<Tensor> tensors;
+  std::vector<ConvLayer> convs;
+  std::vector<ConvTLayer> convts;
+  std::vector<Op> ops;
+  int n_blob_layers = 0;          // header[4] of a matching blob
+  int t_in8 = -1, t_head_in = -1;
+  int head_cx = 32;
   size_t head_w_off = 0, head_b_off = 0;
   // profiling
   bool prof_on = false;
@@ -82,7 +113,7 @@ struct unetpp_engine {
   int prof_prev_ev = -1;          // end event of the previous launch on the same stream, -1 = none
   hipStream_t prof_prev_stream = nullptr;
   int last_b = 0, last_h = 0, last_w = 0;
-  bool keep_all = false;   // debug: materialise x0_4 and run the head as its own kernel
+  bool keep_all = false;   // debug: materialise the head's input and run the head as its own kernel
   // concurrent micro-batches: `nstreams` copies of the activation area, one internal stream each
   int nstreams = 1;
   size_t act_bytes = 0;          // size of one activation area (slot)
@@ -109,15 +140,37 @@ int fail(unetpp_engine* e, int code, const char* fmt, ...) {
     if (_s != hipSuccess) return fail(e, UNETPP_E_HIP, "%s: %s", #call, hipGetErrorString(_s)); \
   } while (0)
 
-size_t blob_payload_floats(int C, int cin) {
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// payload floats of the canonical blob and number of layers in it
+size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
   size_t n = 0;
-  int ci[9] = {cin, NB[0], NB[1], NB[2], NB[3], NB[3] + NB[4], NB[2] + NB[3], NB[1] + NB[2], NB[0] + NB[1]};
-  int co[9] = {NB[0], NB[1], NB[2], NB[3], NB[4], NB[3], NB[2], NB[1], NB[0]};
-  for (int b = 0; b < 9; ++b) {
-    n += (size_t)co[b] * ci[b] * 9 + co[b];
-    n += (size_t)co[b] * co[b] * 9 + co[b];
+  int layers = 0;
+  if (arch == UNETPP_ARCH_NESTED) {
+    int ci[9] = {cin, NB[0], NB[1], NB[2], NB[3], NB[3] + NB[4], NB[2] + NB[3], NB[1] + NB[2], NB[0] + NB[1]};
+    int co[9] = {NB[0], NB[1], NB[2], NB[3], NB[4], NB[3], NB[2], NB[1], NB[0]};
+    for (int b = 0; b < 9; ++b) {
+      n += (size_t)co[b] * ci[b] * 9 + co[b];
+      n += (size_t)co[b] * co[b] * 9 + co[b];
+      layers += 2;
+    }
+    n += (size_t)C * NB[0] + C;
+    layers += 1;
+  } else {
+    for (int l = 0; l < 4; ++l) {          // enc1..enc4
+      int ci = l == 0 ? cin : SB[l - 1];
+      n += (size_t)SB[l] * ci * 9 + SB[l] + (size_t)SB[l] * SB[l] * 9 + SB[l];
+      layers += 2;
+    }
+    for (int l = 2; l >= 0; --l) { n += (size_t)SB[l + 1] * SB[l] * 4 + SB[l]; layers += 1; }   // up3, up2, up1
+    for (int l = 2; l >= 0; --l) {         // dec3, dec2, dec1
+      n += (size_t)SB[l] * (2 * SB[l]) * 9 + SB[l] + (size_t)SB[l] * SB[l] * 9 + SB[l];
+      layers += 2;
+    }
+    n += (size_t)C * SB[0] + C;
+    layers += 1;
   }
-  n += (size_t)C * NB[0] + C;
+  if (n_layers) *n_layers = layers;
   return n;
 }
 
@@ -154,6 +207,7 @@ hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, 
   CASE(1, 16, 1, 2, 8)
   CASE(1, 32, 1, 2, 4)
   CASE(1, 32, 2, 2, 8)
+  CASE(1, 16, 2, 2, 8)
   CASE(1, 16, 4, 2, 8)
   CASE(2, 16, 1, 2, 8)
   CASE(2, 16, 2, 2, 8)
@@ -161,25 +215,18 @@ hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, 
   return hipErrorInvalidValue;
 }
 
-void choose_cfg(int P, ConvLayer& L) {
+void choose_cfg(int P, int cin_tensor, ConvLayer& L) {
   L.MW = 2; L.WAVES = 8;
-  const int cin = L.in.C + L.in2.C;
   if (P == 1) {
-    if (L.cout == 32) { L.NW = 1; L.KC = (cin <= 16) ? 16 : 32; if (L.KC == 32) L.WAVES = 4; }
-    else if (L.cout == 64) { L.NW = 2; L.KC = 32; }
+    if (L.cout == 32) { L.NW = 1; L.KC = (cin_tensor <= 16) ? 16 : 32; if (L.KC == 32) L.WAVES = 4; }
+    else if (L.cout == 64) { L.NW = 2; L.KC = (cin_tensor <= 16) ? 16 : 32; }
     else { L.NW = 4; L.KC = 16; }
   } else {
     L.KC = 16;
     L.NW = (L.cout == 32) ? 1 : 2;
   }
-  L.nchunks = (L.in.C + L.KC - 1) / L.KC + L.in2.C / L.KC;
 }
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-}  // namespace
-
-namespace {
 struct Launcher {
   unetpp_engine* e;
   hipStream_t s;
@@ -217,27 +264,152 @@ struct Launcher {
     if (st != hipSuccess) rc = fail(e, UNETPP_E_HIP, "launch %s: %s", name.c_str(), hipGetErrorString(st));
   }
 };
+
+// ---- graph construction ------------------------------------------------------------------------
+struct Builder {
+  unetpp_engine* e;
+  size_t act = 0;     // bytes of one activation slot so far
+  size_t off = 0;     // floats of the blob payload so far
+  int tensor(const std::string& name, int C, int lvl) {
+    Tensor t;
+    t.name = name; t.C = C; t.lvl = lvl; t.off = act;
+    const unetpp_config& c = e->cfg;
+    size_t px = (size_t)e->mb * (c.max_h >> lvl) * (c.max_w >> lvl);
+    act += align_up(px * e->P * C * sizeof(half_t), 256);
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+  }
+  int conv(const std::string& name, int cin_real, int in, int in2, int out, bool pool_to = false, int pool = -1) {
+    ConvLayer L;
+    L.name = name; L.cin_real = cin_real; L.in = in; L.in2 = in2; L.out = out; L.pool = pool; L.do_pool = pool_to;
+    L.cout = e->tensors[out].C; L.lvl = e->tensors[out].lvl;
+    L.w_off = off; off += (size_t)L.cout * cin_real * 9;
+    L.b_off = off; off += L.cout;
+    const int c0 = e->tensors[in].C, c1 = in2 >= 0 ? e->tensors[in2].C : 0;
+    choose_cfg(e->P, c0 + c1, L);
+    L.nchunks = (c0 + L.KC - 1) / L.KC + c1 / L.KC;
+    e->convs.push_back(L);
+    Op op; op.kind = OP_CONV; op.idx = (int)e->convs.size() - 1;
+    e->ops.push_back(op);
+    return op.idx;
+  }
+  void convt(const std::string& name, int in, int out) {
+    ConvTLayer T;
+    T.name = name; T.in = in; T.out = out; T.cin = e->tensors[in].C; T.cout = e->tensors[out].C; T.lvl = e->tensors[in].lvl;
+    T.w_off = off; off += (size_t)T.cin * T.cout * 4;
+    T.b_off = off; off += T.cout;
+    e->convts.push_back(T);
+    Op op; op.kind = OP_CONVT; op.idx = (int)e->convts.size() - 1;
+    e->ops.push_back(op);
+  }
+  void up(int src, int dst) { Op op; op.kind = OP_UP; op.idx = src; op.out = dst; e->ops.push_back(op); }
+  void head(int in, int cx) {
+    e->t_head_in = in; e->head_cx = cx;
+    e->head_w_off = off; off += (size_t)e->cfg.num_classes * cx;
+    e->head_b_off = off; off += e->cfg.num_classes;
+    Op op; op.kind = OP_HEAD; op.out = in; e->ops.push_back(op);
+  }
+};
+
+void build_nested(unetpp_engine* e, Builder& b) {
+  Op cv; cv.kind = OP_CONVERT; e->ops.push_back(cv);
+  e->t_in8 = b.tensor("in8", 8, 0);
+  int x[5], xa[5], pooled[4], up[4], d[4], da[4];
+  for (int l = 0; l < 5; ++l) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "x%d_0", l);
+    xa[l] = b.tensor(std::string(nm) + "a", NB[l], l);
+    x[l] = b.tensor(nm, NB[l], l);
+    if (l < 4) pooled[l] = b.tensor(std::string(nm) + "p", NB[l], l + 1);
+    snprintf(nm, sizeof nm, "conv%d_0", l);
+    b.conv(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->t_in8 : pooled[l - 1], -1, xa[l]);
+    b.conv(std::string(nm) + ".conv2", NB[l], xa[l], -1, x[l], l < 4, l < 4 ? pooled[l] : -1);
+  }
+  for (int l = 3; l >= 0; --l) {
+    char nm[32], tn[32];
+    snprintf(tn, sizeof tn, "x%d_%d", l, 4 - l);
+    up[l] = b.tensor(std::string(tn) + "u", NB[l + 1], l);
+    da[l] = b.tensor(std::string(tn) + "a", NB[l], l);
+    d[l] = b.tensor(tn, NB[l], l);
+    b.up(l == 3 ? x[4] : d[l + 1], up[l]);
+    snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
+    b.conv(std::string(nm) + ".conv1", NB[l] + NB[l + 1], x[l], up[l], da[l]);     // cat([skip, up]) (unetpp.py:112-116)
+    b.conv(std::string(nm) + ".conv2", NB[l], da[l], -1, d[l]);
+    if (l == 0) e->ops.back().fuse_head = true;
+  }
+  b.head(d[0], NB[0]);
+}
+
+void build_simple(unetpp_engine* e, Builder& b) {
+  Op cv; cv.kind = OP_CONVERT; e->ops.push_back(cv);
+  e->t_in8 = b.tensor("in8", 8, 0);
+  int enc[4], enca[4], pooled[3];
+  for (int l = 0; l < 4; ++l) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "enc%d", l + 1);
+    enca[l] = b.tensor(std::string(nm) + "a", SB[l], l);
+    enc[l] = b.tensor(nm, SB[l], l);
+    if (l < 3) pooled[l] = b.tensor(std::string(nm) + "p", SB[l], l + 1);
+    b.conv(std::string(nm) + ".0", l == 0 ? 3 : SB[l - 1], l == 0 ? e->t_in8 : pooled[l - 1], -1, enca[l]);
+    b.conv(std::string(nm) + ".2", SB[l], enca[l], -1, enc[l], l < 3, l < 3 ? pooled[l] : -1);
+  }
+  // The canonical blob follows the module DEFINITION order (enc*, up3, up2, up1, dec3, dec2, dec1, final) while
+  // the forward interleaves up/dec: blob offsets are assigned here in definition order, ops in forward order.
+  size_t up_w[3], up_b[3], dec_w[3][2], dec_b[3][2];
+  size_t off = b.off;
+  for (int l = 2; l >= 0; --l) { up_w[l] = off; off += (size_t)SB[l + 1] * SB[l] * 4; up_b[l] = off; off += SB[l]; }
+  for (int l = 2; l >= 0; --l) {
+    dec_w[l][0] = off; off += (size_t)SB[l] * 2 * SB[l] * 9; dec_b[l][0] = off; off += SB[l];
+    dec_w[l][1] = off; off += (size_t)SB[l] * SB[l] * 9; dec_b[l][1] = off; off += SB[l];
+  }
+  int prev = enc[3];
+  for (int l = 2; l >= 0; --l) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "up%d", l + 1);
+    int u = b.tensor(std::string(nm) + "t", SB[l], l);
+    b.convt(nm, prev, u);
+    e->convts.back().w_off = up_w[l]; e->convts.back().b_off = up_b[l];
+    snprintf(nm, sizeof nm, "dec%d", l + 1);
+    int da = b.tensor(std::string(nm) + "a", SB[l], l);
+    int d = b.tensor(nm, SB[l], l);
+    int c1 = b.conv(std::string(nm) + ".0", 2 * SB[l], u, enc[l], da);        // cat([up, enc]) (simple_unet.py:112,117,122)
+    e->convs[c1].w_off = dec_w[l][0]; e->convs[c1].b_off = dec_b[l][0];
+    int c2 = b.conv(std::string(nm) + ".2", SB[l], da, -1, d);
+    e->convs[c2].w_off = dec_w[l][1]; e->convs[c2].b_off = dec_b[l][1];
+    prev = d;
+  }
+  b.off = off;
+  b.head(prev, SB[0]);
+}
+
 }  // namespace
 
 extern "C" {
 
-const char* unetpp_version(void) { return "unetpp-hip 0.1.0 (gfx950)"; }
+const char* unetpp_version(void) { return "unetpp-hip 0.2.0 (gfx950)"; }
 
 const char* unetpp_last_error(const unetpp_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
 size_t unetpp_weights_blob_bytes(int num_classes, int in_channels) {
-  return 32 + 4 * blob_payload_floats(num_classes, in_channels);
+  return 32 + 4 * blob_payload_floats(UNETPP_ARCH_NESTED, num_classes, in_channels);
+}
+
+size_t unetpp_weights_blob_bytes_arch(int arch, int num_classes, int in_channels) {
+  if (arch != UNETPP_ARCH_NESTED && arch != UNETPP_ARCH_SIMPLE) return 0;
+  return 32 + 4 * blob_payload_floats(arch, num_classes, in_channels);
 }
 
 int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (!cfg || !out) return fail(nullptr, UNETPP_E_INVALID, "null argument");
   *out = nullptr;
+  if (cfg->arch != UNETPP_ARCH_NESTED && cfg->arch != UNETPP_ARCH_SIMPLE) return fail(nullptr, UNETPP_E_INVALID, "arch=%d unknown", cfg->arch);
   if (cfg->in_channels != 3) return fail(nullptr, UNETPP_E_UNSUPPORTED, "input_channels=%d unsupported (only 3)", cfg->in_channels);
-  if (cfg->num_classes < 1 || cfg->num_classes > HEAD_MAX_CLASSES)
-    return fail(nullptr, UNETPP_E_INVALID, "num_classes=%d out of range [1,%d]", cfg->num_classes, HEAD_MAX_CLASSES);
-  if (cfg->max_batch < 1 || cfg->max_h < 16 || cfg->max_w < 16 || cfg->max_h % 16 || cfg->max_w % 16)
-    return fail(nullptr, UNETPP_E_INVALID, "max shape (%d,%d,%d): batch>=1 and H,W positive multiples of 16 required",
-                cfg->max_batch, cfg->max_h, cfg->max_w);
+  if (cfg->num_classes < 1 || cfg->num_classes > HEAD_FUSED_MAX_CLASSES)
+    return fail(nullptr, UNETPP_E_INVALID, "num_classes=%d out of range [1,%d]", cfg->num_classes, HEAD_FUSED_MAX_CLASSES);
+  const int mult = cfg->arch == UNETPP_ARCH_NESTED ? 16 : 8;      // 4 resp. 3 poolings
+  if (cfg->max_batch < 1 || cfg->max_h < mult || cfg->max_w < mult || cfg->max_h % mult || cfg->max_w % mult)
+    return fail(nullptr, UNETPP_E_INVALID, "max shape (%d,%d,%d): batch>=1 and H,W positive multiples of %d required",
+                cfg->max_batch, cfg->max_h, cfg->max_w, mult);
   if (cfg->precision != UNETPP_PREC_EXACT && cfg->precision != UNETPP_PREC_FAST)
     return fail(nullptr, UNETPP_E_INVALID, "precision=%d unknown", cfg->precision);
   int ndev = 0;
@@ -258,55 +430,18 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
   const int P = e->P;
 
-  // ---- tensor plan (sizes for micro-batch x max_h x max_w)
-  std::vector<std::pair<Tensor*, size_t>> allocs;
-  size_t total = 0;
-  auto plan = [&](Tensor& t, int C, int lvl) {
-    t.C = C; t.lvl = lvl;
-    size_t px = (size_t)e->mb * (cfg->max_h >> lvl) * (cfg->max_w >> lvl);
-    size_t bytes = align_up(px * P * C * sizeof(half_t), 256);
-    allocs.push_back({&t, total});
-    total += bytes;
-  };
-  plan(e->in8, 8, 0);
-  for (int l = 0; l < 5; ++l) { plan(e->xa[l], NB[l], l); plan(e->x[l], NB[l], l); }
-  for (int l = 0; l < 4; ++l) plan(e->pooled[l], NB[l], l + 1);
-  for (int l = 0; l < 4; ++l) { plan(e->up[l], NB[l + 1], l); plan(e->da[l], NB[l], l); plan(e->d[l], NB[l], l); }
-
-  e->act_bytes = align_up(total, 4096);
-  total = e->act_bytes * e->nstreams;
-
-  // ---- conv layers in forward order; canonical blob offsets
-  size_t off = 0;
-  Tensor none;
-  auto add = [&](const std::string& name, int cin_real, const Tensor& in, const Tensor& in2, const Tensor& outT, int lvl, bool pool) {
-    ConvLayer L;
-    L.name = name; L.cin_real = cin_real; L.in = in; L.in2 = in2; L.out = outT; L.cout = outT.C; L.lvl = lvl;
-    L.do_pool = pool;
-    L.w_off = off; off += (size_t)L.cout * cin_real * 9;
-    L.b_off = off; off += L.cout;
-    choose_cfg(P, L);
-    e->convs.push_back(L);
-  };
-  for (int l = 0; l < 5; ++l) {
-    char nm[32];
-    snprintf(nm, sizeof nm, "conv%d_0", l);
-    add(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->in8 : e->pooled[l - 1], none, e->xa[l], l, false);
-    add(std::string(nm) + ".conv2", NB[l], e->xa[l], none, e->x[l], l, l < 4);
+  Builder b{e};
+  if (cfg->arch == UNETPP_ARCH_NESTED) build_nested(e, b); else build_simple(e, b);
+  e->blob_floats = b.off;
+  if (b.off != blob_payload_floats(cfg->arch, cfg->num_classes, 3, &e->n_blob_layers)) {
+    delete e;
+    return fail(nullptr, UNETPP_E_STATE, "internal: blob size mismatch");
   }
-  for (int l = 3; l >= 0; --l) {
-    char nm[32];
-    snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
-    add(std::string(nm) + ".conv1", NB[l] + NB[l + 1], l == 3 ? e->x[3] : e->x[l], e->up[l], e->da[l], l, false);
-    add(std::string(nm) + ".conv2", NB[l], e->da[l], none, e->d[l], l, false);
-  }
-  e->head_w_off = off; off += (size_t)cfg->num_classes * NB[0];
-  e->head_b_off = off; off += cfg->num_classes;
-  e->blob_floats = off;
-  if (off != blob_payload_floats(cfg->num_classes, 3)) { delete e; return fail(nullptr, UNETPP_E_STATE, "internal: blob size mismatch"); }
+  e->act_bytes = align_up(b.act, 4096);
+  size_t total = e->act_bytes * e->nstreams;
 
-  // ---- packed weights + scales + blob in the same arena
-  size_t blob_off = total; total += align_up(off * sizeof(float), 256);
+  // ---- blob + packed weights + scales in the same arena
+  size_t blob_off = total; total += align_up(b.off * sizeof(float), 256);
   std::vector<size_t> wpk_off(e->convs.size()), sc_off(e->convs.size()), mu_off(e->convs.size());
   for (size_t i = 0; i < e->convs.size(); ++i) {
     ConvLayer& L = e->convs[i];
@@ -315,6 +450,13 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     sc_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
     mu_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
   }
+  std::vector<size_t> twpk(e->convts.size()), tsc(e->convts.size()), tmu(e->convts.size());
+  for (size_t i = 0; i < e->convts.size(); ++i) {
+    ConvTLayer& T = e->convts[i];
+    twpk[i] = total; total += align_up((size_t)4 * T.cout * T.cin * P * sizeof(half_t), 256);
+    tsc[i] = total; total += align_up(T.cout * sizeof(float), 256);
+    tmu[i] = total; total += align_up(T.cout * sizeof(float), 256);
+  }
   hipError_t st = hipMalloc((void**)&e->arena, total);
   if (st != hipSuccess) {
     std::string m = hipGetErrorString(st);
@@ -322,24 +464,16 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     return fail(nullptr, UNETPP_E_HIP, "hipMalloc(%zu bytes): %s", total, m.c_str());
   }
   e->arena_bytes = total;
-  for (auto& a : allocs) a.first->p = (half_t*)(e->arena + a.second);
   e->blob = (float*)(e->arena + blob_off);
   for (size_t i = 0; i < e->convs.size(); ++i) {
     e->convs[i].wpk = (half_t*)(e->arena + wpk_off[i]);
     e->convs[i].scale = (float*)(e->arena + sc_off[i]);
     e->convs[i].mult = (float*)(e->arena + mu_off[i]);
   }
-  // tensor pointers were copied into layers before allocation: rebind
-  {
-    size_t i = 0;
-    for (int l = 0; l < 5; ++l) {
-      e->convs[i].in = (l == 0) ? e->in8 : e->pooled[l - 1]; e->convs[i].out = e->xa[l]; ++i;
-      e->convs[i].in = e->xa[l]; e->convs[i].out = e->x[l]; if (l < 4) e->convs[i].pool = e->pooled[l]; ++i;
-    }
-    for (int l = 3; l >= 0; --l) {
-      e->convs[i].in = e->x[l]; e->convs[i].in2 = e->up[l]; e->convs[i].out = e->da[l]; ++i;
-      e->convs[i].in = e->da[l]; e->convs[i].out = e->d[l]; ++i;
-    }
+  for (size_t i = 0; i < e->convts.size(); ++i) {
+    e->convts[i].wpk = (half_t*)(e->arena + twpk[i]);
+    e->convts[i].scale = (float*)(e->arena + tsc[i]);
+    e->convts[i].mult = (float*)(e->arena + tmu[i]);
   }
   if (e->nstreams > 1) {
     for (int i = 0; i < e->nstreams; ++i) {
@@ -374,18 +508,26 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
                        L.cout, P, L.KC, BN, L.nchunks, L.wpk, units);
   }
+  for (auto& T : e->convts) {
+    const float* w = e->blob + T.w_off;
+    hipLaunchKernelGGL(convt_scale_kernel, dim3(T.cout), dim3(256), 0, s, w, T.cin, T.cout, T.mult, T.scale);
+    long long units = (long long)(4 * T.cout / 32) * (T.cin / 16) * P * 64;
+    hipLaunchKernelGGL(convt_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, T.mult, T.cin, T.cout, P,
+                       T.wpk, units);
+  }
   HIP_TRY(e, hipGetLastError());
   e->weights_loaded = true;
   return UNETPP_OK;
 }
 
 static int check_header(unetpp_engine* e, const uint32_t* h, size_t bytes) {
-  if (bytes != unetpp_weights_blob_bytes(e->cfg.num_classes, e->cfg.in_channels))
-    return fail(e, UNETPP_E_INVALID, "weight blob is %zu bytes, expected %zu for num_classes=%d", bytes,
-                unetpp_weights_blob_bytes(e->cfg.num_classes, e->cfg.in_channels), e->cfg.num_classes);
+  const size_t want = unetpp_weights_blob_bytes_arch(e->cfg.arch, e->cfg.num_classes, e->cfg.in_channels);
+  if (bytes != want)
+    return fail(e, UNETPP_E_INVALID, "weight blob is %zu bytes, expected %zu for arch=%d num_classes=%d", bytes, want, e->cfg.arch,
+                e->cfg.num_classes);
   if (h[0] != BLOB_MAGIC || (int)h[1] != BLOB_VERSION) return fail(e, UNETPP_E_INVALID, "bad weight blob magic/version");
-  if ((int)h[2] != e->cfg.num_classes || (int)h[3] != e->cfg.in_channels || (int)h[4] != 19)
-    return fail(e, UNETPP_E_INVALID, "weight blob is for num_classes=%u in_channels=%u convs=%u", h[2], h[3], h[4]);
+  if ((int)h[2] != e->cfg.num_classes || (int)h[3] != e->cfg.in_channels || (int)h[4] != e->n_blob_layers || (int)h[5] != e->cfg.arch)
+    return fail(e, UNETPP_E_INVALID, "weight blob is for num_classes=%u in_channels=%u layers=%u arch=%u", h[2], h[3], h[4], h[5]);
   return UNETPP_OK;
 }
 
@@ -417,7 +559,6 @@ int unetpp_load_weights_device(unetpp_engine* e, const void* dev_blob, size_t by
 }
 
 // ---- forward -------------------------------------------------------------------------------------
-
 int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w, float* dev_logits,
                    uint8_t* dev_mask, uint8_t* dev_cable, uint8_t* dev_tape, void* stream) {
   unetpp_outputs o{};
@@ -433,17 +574,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
   float* dev_logits = outp->dev_logits; float* dev_probs = outp->dev_probs;
   uint8_t* dev_mask = outp->dev_mask; uint8_t* dev_cable = outp->dev_cable; uint8_t* dev_tape = outp->dev_tape;
   if (outp->rule < UNETPP_RULE_ARGMAX || outp->rule > UNETPP_RULE_EXCLUSIVE) return fail(e, UNETPP_E_INVALID, "unknown rule %d", outp->rule);
-  const bool want_probs = dev_probs != nullptr || outp->rule != UNETPP_RULE_ARGMAX;
   if (outp->rule != UNETPP_RULE_ARGMAX && e->cfg.num_classes < 3)
     return fail(e, UNETPP_E_INVALID, "class rules need num_classes >= 3 (bg, cable, tape)");
-  if (want_probs && (e->keep_all || e->cfg.num_classes > HEAD_FUSED_MAX_CLASSES))
-    return fail(e, UNETPP_E_UNSUPPORTED, "probabilities / class rules run only in the fused head (num_classes <= %d, debug keep off)", HEAD_FUSED_MAX_CLASSES);
   if (!dev_input) return fail(e, UNETPP_E_INVALID, "input is NULL");
   if (!e->weights_loaded) return fail(e, UNETPP_E_STATE, "forward before load_weights");
   if (in_format != UNETPP_IN_F32_NCHW && in_format != UNETPP_IN_U8_NHWC_BGR) return fail(e, UNETPP_E_INVALID, "unknown input format %d", in_format);
   if (batch < 1 || batch > e->cfg.max_batch) return fail(e, UNETPP_E_INVALID, "batch %d not in [1,%d]", batch, e->cfg.max_batch);
-  if (h < 16 || w < 16 || h % 16 || w % 16)
-    return fail(e, UNETPP_E_INVALID, "Sizes of tensors must match: H=%d W=%d must be positive multiples of 16", h, w);
+  const int mult = e->cfg.arch == UNETPP_ARCH_NESTED ? 16 : 8;
+  if (h < mult || w < mult || h % mult || w % mult)
+    return fail(e, UNETPP_E_INVALID, "Sizes of tensors must match: H=%d W=%d must be positive multiples of %d", h, w, mult);
   if (h > e->cfg.max_h || w > e->cfg.max_w) return fail(e, UNETPP_E_INVALID, "shape %dx%d exceeds engine maximum %dx%d", h, w, e->cfg.max_h, e->cfg.max_w);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   hipStream_t user_stream = (hipStream_t)stream;
@@ -466,79 +605,98 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     if (multi) { s = e->streams[slot]; Lx.s = s; }
     const size_t slot_off = (size_t)slot * e->act_bytes;
     e->last_slot_off = slot_off;
-    auto sp = [&](const Tensor& t) { return (half_t*)((char*)t.p + slot_off); };
-    // 1. input conversion
-    {
-      const char* src = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
-      size_t total = (size_t)nb * hw;
-      double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
-      Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, sp(e->in8));
-        else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, sp(e->in8));
-        return hipSuccess;
-      });
-    }
+    auto tp = [&](int id) { return (half_t*)(e->arena + slot_off + e->tensors[id].off); };
     float* lg = dev_logits ? dev_logits + (size_t)b0 * C * hw : nullptr;
     uint8_t* mk = dev_mask ? dev_mask + (size_t)b0 * hw : nullptr;
     uint8_t* cb = dev_cable ? dev_cable + (size_t)b0 * hw : nullptr;
-    uint8_t* tp = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
+    uint8_t* tpe = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
     float* pr = dev_probs ? dev_probs + (size_t)b0 * C * hw : nullptr;
-    const bool fuse_head = !e->keep_all && C <= HEAD_FUSED_MAX_CLASSES;
-    auto run_conv = [&](ConvLayer& L, bool head) {
-      ConvArgs a{};
-      const int H = h >> L.lvl, W = w >> L.lvl;
-      a.in0 = sp(L.in); a.in1 = L.in2.C ? sp(L.in2) : nullptr; a.C0 = L.in.C; a.C1 = L.in2.C;
-      a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = sp(L.out);
-      a.pool_out = L.do_pool ? sp(L.pool) : nullptr;
-      a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
-      const int TH = L.WAVES * L.MW;
-      a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
-      a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
-      double px = (double)nb * H * W;
-      double flops = 2.0 * px * L.cout * L.cin_real * 9;
-      double bytes = px * P * 2.0 * (L.in.C + L.in2.C + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
-      if (head) {
-        a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
-        a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tp;
-        a.probs = pr; a.rule = outp->rule;
-        a.t_cable = outp->t_cable; a.t_tape = outp->t_tape; a.bg_margin = outp->bg_margin; a.ct_margin = outp->ct_margin;
-        flops += 2.0 * px * 32 * C;
-        bytes += px * ((lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
+    bool head_done = false;
+
+    for (const Op& op : e->ops) {
+      if (op.kind == OP_CONVERT) {
+        const char* src = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
+        size_t total = (size_t)nb * hw;
+        double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
+        Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
+          if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8));
+          else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8));
+          return hipSuccess;
+        });
+      } else if (op.kind == OP_CONV) {
+        ConvLayer& L = e->convs[op.idx];
+        const bool head = op.fuse_head && !e->keep_all && L.cout == 32;
+        ConvArgs a{};
+        const int H = h >> L.lvl, W = w >> L.lvl;
+        const Tensor& t0 = e->tensors[L.in];
+        const int c1 = L.in2 >= 0 ? e->tensors[L.in2].C : 0;
+        a.in0 = tp(L.in); a.in1 = L.in2 >= 0 ? tp(L.in2) : nullptr; a.C0 = t0.C; a.C1 = c1;
+        a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = tp(L.out);
+        a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
+        a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
+        const int TH = L.WAVES * L.MW;
+        a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
+        a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
+        double px = (double)nb * H * W;
+        double flops = 2.0 * px * L.cout * L.cin_real * 9;
+        double bytes = px * P * 2.0 * (t0.C + c1 + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+        if (head) {
+          a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
+          a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tpe;
+          a.probs = pr; a.rule = outp->rule;
+          a.t_cable = outp->t_cable; a.t_tape = outp->t_tape; a.bg_margin = outp->bg_margin; a.ct_margin = outp->ct_margin;
+          flops += 2.0 * px * 32 * C;
+          bytes += px * ((lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tpe ? 1 : 0));
+          head_done = true;
+        }
+        char lbl[128];
+        snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
+        Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, head, s); });
+      } else if (op.kind == OP_UP) {
+        const Tensor& low = e->tensors[op.idx];
+        const Tensor& dst = e->tensors[op.out];
+        const int H = h >> dst.lvl, W = w >> dst.lvl;
+        double px = (double)nb * H * W;
+        double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
+        // enough waves per LDS byte: the staged rows take 3*(W/2)*P*32 bytes per workgroup
+        const int up_threads = (3 * (W / 2) * P * 32 > 32 * 1024) ? 1024 : (3 * (W / 2) * P * 32 > 12 * 1024 ? 512 : 256);
+        char nm[64];
+        snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", dst.lvl, P);
+        Lx.run(nm, px * low.C * 8, bytes, [&] {
+          if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 2 * 32, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
+          else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 1 * 32, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
+          return hipSuccess;
+        });
+      } else if (op.kind == OP_CONVT) {
+        ConvTLayer& T = e->convts[op.idx];
+        ConvTArgs a{};
+        const int H = h >> T.lvl, W = w >> T.lvl;
+        a.in = tp(T.in); a.wpk = T.wpk; a.scale = T.scale; a.bias = e->blob + T.b_off; a.out = tp(T.out);
+        a.N = nb; a.H = H; a.W = W; a.Cin = T.cin; a.Cout = T.cout;
+        double px = (double)nb * H * W;
+        double flops = 2.0 * px * T.cin * T.cout * 4;
+        double bytes = px * P * 2.0 * (T.cin + 4.0 * T.cout) + 4.0 * T.cin * T.cout * 2.0 * P;
+        dim3 grid((unsigned)((H * W + 511) / 512), (unsigned)(4 * T.cout / 64), (unsigned)nb);
+        char lbl[96];
+        snprintf(lbl, sizeof lbl, "%s|convt2x2_kernel<%d>", T.name.c_str(), P);
+        Lx.run(lbl, flops, bytes, [&] {
+          if (P == 2) hipLaunchKernelGGL(convt2x2_kernel<2>, grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL(convt2x2_kernel<1>, grid, dim3(256), 0, s, a);
+          return hipSuccess;
+        });
+      } else if (op.kind == OP_HEAD) {
+        if (head_done) continue;     // ran in the last conv's epilogue
+        const int cx = e->head_cx;
+        size_t total = (size_t)nb * hw;
+        double bytes = (double)total * (P * 2.0 * cx + (lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tpe ? 1 : 0));
+        dim3 grid((unsigned)((hw + 255) / 256), (unsigned)nb);
+        const size_t lds = (size_t)(C * cx + C) * sizeof(float);
+        Lx.run(P == 2 ? "final+argmax|head_generic_kernel<2>" : "final+argmax|head_generic_kernel<1>", 2.0 * total * cx * C, bytes, [&] {
+          if (P == 2) hipLaunchKernelGGL(head_generic_kernel<2>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+          else hipLaunchKernelGGL(head_generic_kernel<1>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+          return hipSuccess;
+        });
       }
-      char lbl[112];
-      snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
-      Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, head, s); });
-    };
-    auto run_up = [&](int l, const Tensor& low) {
-      const int H = h >> l, W = w >> l;
-      double px = (double)nb * H * W;
-      double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
-      // enough waves per LDS byte: the staged rows take 3*(W/2)*P*32 bytes per workgroup
-      const int up_threads = (3 * (W / 2) * P * 32 > 32 * 1024) ? 1024 : (3 * (W / 2) * P * 32 > 12 * 1024 ? 512 : 256);
-      char nm[64];
-      snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", l, P);
-      Lx.run(nm, px * low.C * 8, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 2 * 32, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
-        else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 1 * 32, s, sp(low), low.C, nb, H, W, sp(e->up[l]));
-        return hipSuccess;
-      });
-    };
-    size_t li = 0;
-    for (int l = 0; l < 5; ++l) { run_conv(e->convs[li], false); ++li; run_conv(e->convs[li], false); ++li; }
-    for (int l = 3; l >= 0; --l) {
-      run_up(l, l == 3 ? e->x[4] : e->d[l + 1]);
-      run_conv(e->convs[li], false); ++li;
-      run_conv(e->convs[li], l == 0 && fuse_head); ++li;
-    }
-    // head as its own kernel only in debug mode (normally fused into conv0_4.conv2's epilogue)
-    if (!fuse_head) {
-      size_t total = (size_t)nb * hw;
-      double bytes = (double)total * (P * 64 + (lg ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tp ? 1 : 0));
-      Lx.run(P == 2 ? "final+argmax|head_argmax_kernel<2>" : "final+argmax|head_argmax_kernel<1>", 2.0 * total * 32 * C, bytes, [&] {
-        if (P == 2) hipLaunchKernelGGL(head_argmax_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(e->d[0]), e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
-        else hipLaunchKernelGGL(head_argmax_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, sp(e->d[0]), e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, mk, cb, tp);
-        return hipSuccess;
-      });
     }
     if (Lx.rc) return Lx.rc;
   }
@@ -607,14 +765,12 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   if (!e || !name || !host_out) return UNETPP_E_INVALID;
   if (e->last_b == 0) return fail(e, UNETPP_E_STATE, "debug_read before forward");
   const Tensor* t = nullptr;
-  std::string nm(name);
-  if (nm.size() == 4 && nm[0] == 'x' && nm[2] == '_') {
-    int l = nm[1] - '0', j = nm[3] - '0';
-    if (l >= 0 && l <= 4 && j == 0) t = &e->x[l];
-    else if (l >= 0 && l <= 3 && j == 4 - l) t = &e->d[l];
-  }
+  int tid = -1;
+  for (size_t i = 0; i < e->tensors.size(); ++i)
+    if (e->tensors[i].name == name) { t = &e->tensors[i]; tid = (int)i; }
   if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
-  if (t == &e->d[0] && !e->keep_all && e->cfg.num_classes <= HEAD_FUSED_MAX_CLASSES) return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
+  if (e->cfg.arch == UNETPP_ARCH_NESTED && tid == e->t_head_in && !e->keep_all)
+    return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   int nb = e->last_b % e->mb == 0 ? std::min(e->mb, e->last_b) : e->last_b % e->mb;
   const int H = e->last_h >> t->lvl, W = e->last_w >> t->lvl;
@@ -623,8 +779,9 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   float* tmp = nullptr;
   HIP_TRY(e, hipDeviceSynchronize());
   HIP_TRY(e, hipMalloc((void**)&tmp, total * sizeof(float)));
-  if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, (const half_t*)((const char*)t->p + e->last_slot_off), nb, t->C, H, W, tmp);
-  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, (const half_t*)((const char*)t->p + e->last_slot_off), nb, t->C, H, W, tmp);
+  const half_t* src = (const half_t*)(e->arena + e->last_slot_off + t->off);
+  if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
+  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
   hipError_t st = hipMemcpy(host_out, tmp, total * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(tmp);
   if (st != hipSuccess) return fail(e, UNETPP_E_HIP, "debug copy: %s", hipGetErrorString(st));

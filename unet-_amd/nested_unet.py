@@ -21,6 +21,8 @@ from . import _lib, packing
 
 
 class NestedUNet:
+    _ARCH = _lib.ARCH_NESTED
+    _SIZE_MULTIPLE = 16
     def __init__(self, num_classes: int, input_channels: int = 3, deep_supervision: bool = True,
                  pretrained_encoder: bool = False, *, precision: str = "exact", max_batch: int = 16,
                  max_hw=(512, 512), micro_batch: int = 0, streams: int = 1) -> None:
@@ -120,7 +122,7 @@ class NestedUNet:
         lib = _lib.load()
         cfg = _lib.Config(self.num_classes, self.input_channels, self._max_batch, self._max_hw[0], self._max_hw[1],
                           _lib.PREC_EXACT if self.precision == "exact" else _lib.PREC_FAST, self._device_index,
-                          self._micro_batch, self._streams)
+                          self._micro_batch, self._streams, self._ARCH)
         handle = ctypes.c_void_p()
         rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(handle))
         if rc != 0:
@@ -139,7 +141,7 @@ class NestedUNet:
     def load_weights_from_device_blob(self, blob_tensor):
         """After an RCCL broadcast: `blob_tensor` is a uint8 CUDA tensor holding the canonical blob."""
         import torch
-        self._ensure_engine(1, 16, 16)
+        self._ensure_engine(1, self._SIZE_MULTIPLE, self._SIZE_MULTIPLE)
         rc = _lib.load().unetpp_load_weights_device(self._handle, ctypes.c_void_p(blob_tensor.data_ptr()),
                                                     blob_tensor.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
@@ -168,9 +170,9 @@ class NestedUNet:
             fmt = _lib.IN_U8_NHWC_BGR
         else:
             raise RuntimeError(f"unsupported input dtype {x.dtype}")
-        if h % 16 or w % 16:
+        if h % self._SIZE_MULTIPLE or w % self._SIZE_MULTIPLE:
             # same failure the reference hits inside torch.cat (unetpp.py:112-116) for such sizes
-            raise RuntimeError(f"Sizes of tensors must match: H={h}, W={w} must be multiples of 16")
+            raise RuntimeError(f"Sizes of tensors must match: H={h}, W={w} must be multiples of {self._SIZE_MULTIPLE}")
         if self._device_index is None:
             self.to(x.device)
         if x.device.index != self._device_index:
@@ -274,10 +276,13 @@ class NestedUNet:
         """Materialise x0_4 and run the head unfused (needed before debug_activation('x0_4'))."""
         _lib.load().unetpp_debug_keep_intermediates(self._handle, 1 if on else 0)
 
+    def _node_shape(self, name: str):
+        lvl = int(name[1])
+        return (32, 64, 128, 256, 512)[lvl], lvl
+
     def debug_activation(self, name: str, b: int, h: int, w: int) -> np.ndarray:
         """float32 [b,C,h',w'] copy of an intermediate node ('x0_0'..'x4_0','x3_1','x2_2','x1_3','x0_4')."""
-        lvl = int(name[1])
-        c = (32, 64, 128, 256, 512)[lvl]
+        c, lvl = self._node_shape(name)
         out = np.empty((b, c, h >> lvl, w >> lvl), dtype=np.float32)
         n = _lib.load().unetpp_debug_read(self._handle, name.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), out.size)
         if n < 0:
@@ -285,3 +290,33 @@ class NestedUNet:
         if n != out.size:
             raise RuntimeError(f"debug_read returned {n} floats, expected {out.size}")
         return out
+
+
+class SimpleUNet(NestedUNet):
+    """Drop-in for the reference's ``SimpleUNet`` (src/models/simple_unet.py:20-128), the
+    plain 4-level U-Net of infer_video_simple.py:67: same constructor keywords (num_classes=7, num_channels=3),
+    same state_dict keys (enc1.0 ... final), logits from ``model(x)``; ``predict_proba`` replaces the
+    ``torch.softmax(output, dim=1)`` of infer_video_simple.py:96.  H and W must be multiples of 8."""
+    _ARCH = _lib.ARCH_SIMPLE
+    _SIZE_MULTIPLE = 8
+
+    def __init__(self, num_classes: int = 7, num_channels: int = 3, *, precision: str = "exact", max_batch: int = 16,
+                 max_hw=(256, 256), micro_batch: int = 0, streams: int = 1) -> None:
+        super().__init__(num_classes, num_channels, False, False, precision=precision, max_batch=max_batch,
+                         max_hw=max_hw, micro_batch=micro_batch, streams=streams)
+        self.num_channels = int(num_channels)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        state_dict = packing.unwrap_checkpoint(state_dict)
+        missing, unexpected = packing.check_simple_state_dict(state_dict, self.num_classes, self.num_channels, strict)
+        if missing:
+            raise RuntimeError("Missing key(s) in state_dict: " + ", ".join(missing))
+        self._blob = packing.build_simple_blob(state_dict, self.num_classes, self.num_channels)
+        self._state_dict = {k: packing._np(v).copy() for k, v in state_dict.items()}
+        if self._handle is not None:
+            self._upload()
+        return missing, unexpected
+
+    def _node_shape(self, name: str):
+        lvl = int(name[3]) - 1                      # 'enc1'..'enc4', 'dec1'..'dec3'
+        return (64, 128, 256, 512)[lvl], lvl

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .synthetic import conv_blocks, state_dict_manifest
+from .synthetic import conv_blocks, simple_unet_manifest, state_dict_manifest
 
 BN_EPS = 1e-5
 BLOB_MAGIC = 0x50504E55  # 'UNPP'
@@ -83,9 +83,42 @@ def build_blob(state_dict, num_classes: int, in_channels: int = 3) -> np.ndarray
     """Canonical blob (uint8 array): 32-byte header + fp32 payload; ds* heads and num_batches_tracked are dropped
     (deep-supervision heads run only in train mode, unetpp.py:121-133)."""
     layers = folded_layers(state_dict, in_channels)
-    header = np.array([BLOB_MAGIC, BLOB_VERSION, num_classes, in_channels, len(layers), 0, 0, 0], dtype=np.uint32)
+    header = np.array([BLOB_MAGIC, BLOB_VERSION, num_classes, in_channels, len(layers), 0, 0, 0], dtype=np.uint32)   # arch 0
     parts = [header.view(np.uint8)]
     for _, w, b in layers:
         parts.append(np.ascontiguousarray(w, dtype=np.float32).ravel().view(np.uint8))
         parts.append(np.ascontiguousarray(b, dtype=np.float32).ravel().view(np.uint8))
+    return np.concatenate(parts)
+
+
+# ---------------------------------------------------------------------------- SimpleUNet (SURVEY §8(f) row 3)
+def check_simple_state_dict(state_dict, num_classes: int, num_channels: int = 3, strict: bool = True):
+    """nn.Module.load_state_dict(strict=...) semantics for SimpleUNet (src/models/simple_unet.py:30-92)."""
+    expected = {k: tuple(s) for k, s, _ in simple_unet_manifest(num_classes, num_channels)}
+    missing = [k for k in expected if k not in state_dict]
+    unexpected = [k for k in state_dict if k not in expected]
+    errs = []
+    for k, shp in expected.items():
+        if k in state_dict and tuple(_np(state_dict[k]).shape) != shp:
+            errs.append(f"size mismatch for {k}: copying a param with shape {tuple(_np(state_dict[k]).shape)} "
+                        f"from checkpoint, the shape in current model is {shp}.")
+    if strict and (missing or unexpected):
+        if unexpected:
+            errs.insert(0, "Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ". ")
+        if missing:
+            errs.insert(0, "Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ". ")
+    if errs:
+        raise RuntimeError("Error(s) in loading state_dict for SimpleUNet:\n\t" + "\n\t".join(errs))
+    return missing, unexpected
+
+
+def build_simple_blob(state_dict, num_classes: int, num_channels: int = 3) -> np.ndarray:
+    """Canonical blob for arch 1: the state_dict's tensors in definition order (weights then bias per layer),
+    fp32, nothing folded (SimpleUNet has no BatchNorm)."""
+    man = simple_unet_manifest(num_classes, num_channels)
+    n_layers = len(man) // 2
+    header = np.array([BLOB_MAGIC, BLOB_VERSION, num_classes, num_channels, n_layers, 1, 0, 0], dtype=np.uint32)
+    parts = [header.view(np.uint8)]
+    for key, _, _ in man:
+        parts.append(np.ascontiguousarray(_np(state_dict[key]), dtype=np.float32).ravel().view(np.uint8))
     return np.concatenate(parts)

@@ -79,6 +79,43 @@ def make_state_dict(num_classes: int = 3, in_channels: int = 3, deep_supervision
     return sd
 
 
+SIMPLE_WIDTHS = (64, 128, 256, 512)  # src/models/simple_unet.py:32-57
+
+
+def simple_unet_manifest(num_classes: int = 7, num_channels: int = 3):
+    """Ordered (key, shape, dtype) list identical to SimpleUNet.state_dict() (src/models/simple_unet.py:30-92):
+    enc{1..4}.{0,2}, up3, up2, up1 (ConvTranspose2d: weight [Cin, Cout, 2, 2]), dec{3,2,1}.{0,2}, final."""
+    w = SIMPLE_WIDTHS
+    out = []
+    for l in range(4):
+        ci = num_channels if l == 0 else w[l - 1]
+        out += [(f"enc{l+1}.0.weight", (w[l], ci, 3, 3), "float32"), (f"enc{l+1}.0.bias", (w[l],), "float32"),
+                (f"enc{l+1}.2.weight", (w[l], w[l], 3, 3), "float32"), (f"enc{l+1}.2.bias", (w[l],), "float32")]
+    for l in (2, 1, 0):
+        out += [(f"up{l+1}.weight", (w[l + 1], w[l], 2, 2), "float32"), (f"up{l+1}.bias", (w[l],), "float32")]
+    for l in (2, 1, 0):
+        out += [(f"dec{l+1}.0.weight", (w[l], 2 * w[l], 3, 3), "float32"), (f"dec{l+1}.0.bias", (w[l],), "float32"),
+                (f"dec{l+1}.2.weight", (w[l], w[l], 3, 3), "float32"), (f"dec{l+1}.2.bias", (w[l],), "float32")]
+    out += [("final.weight", (num_classes, w[0], 1, 1), "float32"), ("final.bias", (num_classes,), "float32")]
+    return out
+
+
+def make_simple_state_dict(num_classes: int = 7, num_channels: int = 3, seed: int = 0) -> dict:
+    """He-normal weights (fan_in of the forward contraction), N(0, 0.05^2) biases."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    sd = {}
+    for key, shape, _ in simple_unet_manifest(num_classes, num_channels):
+        if key.endswith("weight"):
+            if key.startswith("up"):
+                fan_in = shape[0]                      # each output pixel sees one tap of every input channel
+            else:
+                fan_in = shape[1] * shape[2] * shape[3]
+            sd[key] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        else:
+            sd[key] = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+    return sd
+
+
 def _bilinear_up(a: np.ndarray, h: int, w: int) -> np.ndarray:
     """Plain half-pixel bilinear resize of a [h0,w0,c] float array (frame synthesis only)."""
     h0, w0 = a.shape[:2]
