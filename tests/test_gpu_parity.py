@@ -345,3 +345,26 @@ def test_simple_unet_fast_and_batch_invariance(torch_cuda, syn, oracle):
         err = float(np.abs(a.cpu().numpy() - ref).max())
         print(f"simple {prec}: max|dlogit|={err:.3e}")
         assert err < tol
+
+
+def test_engine_reuse_smaller_shapes_and_two_engines(torch_cuda, syn, oracle):
+    """One engine sized for 128x160 serves smaller shapes and batches without rebuilding; two engines
+    (different class counts / precisions) coexist on the device."""
+    torch = torch_cuda
+    big, sd = make_model(3, True, 2, "exact", syn, 4, (128, 160))
+    other, sd7 = make_model(7, False, 0, "fast", syn, 2, (64, 64))
+    ws = None
+    for (B, H, W) in ((4, 128, 160), (1, 48, 64), (3, 16, 160), (2, 128, 32)):
+        frames = syn.make_frames_u8(B, H, W, "uniform", H + W)
+        x = syn.frames_to_chw_f32(frames)
+        ref = oracle.torch_forward(sd, x)
+        got = big(torch.from_numpy(x).cuda())
+        m7 = other.segment(torch.zeros(2, 3, 64, 64, device="cuda"))
+        torch.cuda.synchronize()
+        assert float(np.abs(got.cpu().numpy() - ref).max()) < 2e-5
+        assert m7.shape == (2, 64, 64)
+        ws = ws or big.workspace_bytes()                    # engine is created lazily at the first forward
+    assert big.workspace_bytes() == ws                      # never re-created
+    with pytest.raises(RuntimeError, match="too large"):
+        from unet_amd.nested_unet import NestedUNet
+        NestedUNet(3, max_batch=1, max_hw=(8192, 8192)).to("cuda:0")(torch.zeros(1, 3, 16, 16, device="cuda"))

@@ -412,6 +412,10 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
                 cfg->max_batch, cfg->max_h, cfg->max_w, mult);
   if (cfg->precision != UNETPP_PREC_EXACT && cfg->precision != UNETPP_PREC_FAST)
     return fail(nullptr, UNETPP_E_INVALID, "precision=%d unknown", cfg->precision);
+  // the conv loader addresses one image of one tensor with 32-bit byte offsets (buffer loads): the largest
+  // full-resolution tensor has 64 channels x (1 or 2) fp16 planes
+  if ((double)cfg->max_h * cfg->max_w * 64 * 2 * (cfg->precision == UNETPP_PREC_EXACT ? 2 : 1) >= 2147483648.0)
+    return fail(nullptr, UNETPP_E_UNSUPPORTED, "max shape %dx%d too large for 32-bit tensor offsets", cfg->max_h, cfg->max_w);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, UNETPP_E_HIP, "no HIP device available: this engine has no CPU fallback");
