@@ -367,4 +367,6 @@ def test_engine_reuse_smaller_shapes_and_two_engines(torch_cuda, syn, oracle):
     assert big.workspace_bytes() == ws                      # never re-created
     with pytest.raises(RuntimeError, match="too large"):
         from unet_amd.nested_unet import NestedUNet
-        NestedUNet(3, max_batch=1, max_hw=(8192, 8192)).to("cuda:0")(torch.zeros(1, 3, 16, 16, device="cuda"))
+        huge = NestedUNet(3, max_batch=1, max_hw=(8192, 8192)).to("cuda:0")
+        huge.load_state_dict(sd)
+        huge(torch.zeros(1, 3, 16, 16, device="cuda"))
