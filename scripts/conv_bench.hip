@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
   float ms = -1;
 #define CASE(p, kc, nw_, mw, wv) if (P == p && KC == kc && NW == nw_ && MW == mw && WV == wv) ms = run<p, kc, nw_, mw, wv>(a, reps);
   CASE(2, 16, 2, 2, 8) CASE(2, 16, 1, 2, 8) CASE(1, 16, 4, 2, 8) CASE(1, 32, 2, 2, 8) CASE(1, 32, 1, 2, 8)
-  CASE(2, 16, 1, 2, 4) CASE(2, 16, 2, 2, 4) CASE(1, 32, 1, 2, 4) CASE(1, 32, 2, 2, 4) CASE(2, 16, 1, 4, 4) CASE(1, 16, 1, 2, 4) CASE(1, 16, 2, 2, 4)
+  CASE(2, 16, 1, 2, 4) CASE(2, 16, 2, 2, 4) CASE(1, 32, 1, 2, 4) CASE(1, 32, 2, 2, 4) CASE(2, 16, 1, 4, 4) CASE(1, 16, 1, 2, 4) CASE(1, 16, 2, 2, 4) CASE(1, 32, 1, 4, 4) CASE(1, 16, 1, 4, 8) CASE(1, 16, 1, 4, 4) CASE(1, 16, 1, 2, 8)
   double fl = 2.0 * px * a.Cout * (a.C0 + a.C1) * 9;
   printf("MW%d WV%d P%d KC%d NW%d N%d %dx%d C0=%d C1=%d Cout=%d : %.1f us  %.1f TF/s alg (%.1f TF/s MFMA)\n", MW, WV, P, KC, NW, a.N, a.H, a.W, a.C0, a.C1,
          a.Cout, ms * 1e3, fl / ms / 1e9, fl * (P == 2 ? 3 : 1) / ms / 1e9);

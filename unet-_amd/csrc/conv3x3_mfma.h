@@ -442,6 +442,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
           // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: 16 channels in this lane, the other 16
           // in lane ^ 32 (one cross-half shuffle); first maximal class wins.
           const size_t hw = (size_t)H * W;
+          // class logits of both rows: the 16 head weights a lane needs per class are four float4 in LDS
+          // (channels 4h+8q .. +3), read once per class and used for every row of the wave
+          float lgm[MW][HEAD_FUSED_MAX_CLASSES];
+#pragma unroll
+          for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+#pragma unroll
+            for (int m = 0; m < MW; ++m) lgm[m][c] = -INFINITY;
+            if (c < a.head_C) {       // uniform branch
+              float wq[16];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 w4 = *(const float4*)(head_lds + c * 32 + 8 * q + 4 * h);
+                wq[4 * q] = w4.x; wq[4 * q + 1] = w4.y; wq[4 * q + 2] = w4.z; wq[4 * q + 3] = w4.w;
+              }
+              const float bc = head_lds[a.head_C * 32 + c];
+#pragma unroll
+              for (int m = 0; m < MW; ++m) {
+                float part = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part = fmaf(v[m][r], wq[r], part);
+                const float other = __shfl_xor(part, 32, 64);
+                lgm[m][c] = bc + (h == 0 ? part + other : other + part);   // same order in both lanes
+              }
+            }
+          }
 #pragma unroll
           for (int m = 0; m < MW; ++m) {
             const int gy = cur_y0 + wave * MW + m;
@@ -449,16 +474,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
             const size_t pix = (size_t)gy * W + gx;
             float lg[HEAD_FUSED_MAX_CLASSES];
 #pragma unroll
-            for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
-              lg[c] = -INFINITY;
-              if (c < a.head_C) {       // uniform branch
-                float part = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) part = fmaf(v[m][r], head_lds[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h], part);
-                const float other = __shfl_xor(part, 32, 64);
-                lg[c] = head_lds[a.head_C * 32 + c] + (h == 0 ? part + other : other + part);   // same order in both lanes
-              }
-            }
+            for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) lg[c] = lgm[m][c];
             float best = lg[0];
             int besti = 0;
 #pragma unroll

@@ -205,7 +205,6 @@ hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, 
 #define CASE(p, kc, nw, mw, wv) \
   if (P == p && L.KC == kc && L.NW == nw && L.MW == mw && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw, wv>(a, L.do_pool, head, s);
   CASE(1, 16, 1, 2, 8)
-  CASE(1, 32, 1, 2, 4)
   CASE(1, 32, 2, 2, 8)
   CASE(1, 16, 2, 2, 8)
   CASE(1, 16, 4, 2, 8)
@@ -218,7 +217,7 @@ hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, 
 void choose_cfg(int P, int cin_tensor, ConvLayer& L) {
   L.MW = 2; L.WAVES = 8;
   if (P == 1) {
-    if (L.cout == 32) { L.NW = 1; L.KC = (cin_tensor <= 16) ? 16 : 32; if (L.KC == 32) L.WAVES = 4; }
+    if (L.cout == 32) { L.NW = 1; L.KC = 16; }     // 2 workgroups of 8 waves per CU (58 KB LDS each): measured best
     else if (L.cout == 64) { L.NW = 2; L.KC = (cin_tensor <= 16) ? 16 : 32; }
     else { L.NW = 4; L.KC = 16; }
   } else {
