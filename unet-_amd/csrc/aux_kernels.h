@@ -103,13 +103,15 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
 // x is interpolated inside each row first.  The torch.cat([skip, up]) that follows is virtual: the
 // decoder conv reads `skip` and this kernel's output as two sources (conv3x3_mfma.h).
 typedef __attribute__((ext_vector_type(4))) _Float16 half4v;
+constexpr int UP_SEG = 256;                 // output columns per upsample workgroup
 
 template <int P>
 __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
                                                          half_t* __restrict__ out) {
   // Tensors are channel-blocked: [N][Cu/16][h][w][P][16]; a pixel record is 2*P pieces of 16 bytes
   // ([hi 0-7][hi 8-15][lo 0-7][lo 8-15] in EXACT mode).
-  // grid = (H/2, N * Cu/16): one workgroup produces output rows 2r and 2r+1 of one channel block.  The (at
+  // grid = (H/2 * ceil(W/UP_SEG), N * Cu/16): one workgroup produces UP_SEG columns of output rows 2r, 2r+1 of one
+  // channel block.  The (at
   // most three) low-res rows they interpolate are staged ONCE in LDS with full-line loads, so the four
   // corner reads per output are LDS reads: the vector-memory pipe only sees ~1.75 instructions per output
   // KiB instead of 10 (the register version was bound by the address coalescer, not by HBM).
@@ -121,26 +123,32 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
   constexpr int PIECES = 2 * P;
   constexpr int REC = P * 16;                 // halves per pixel record
   extern __shared__ __attribute__((aligned(16))) char up_smem[];
-  half_t* rows = (half_t*)up_smem;            // [3][w][REC]
+  half_t* rows = (half_t*)up_smem;            // [3][wseg][REC]
   const int HP = H >> 1;
-  const int rb = blockIdx.x;
+  // a row pair is cut into column segments of SEG outputs so that the staged rows stay <= 25 KB per
+  // workgroup (enough resident workgroups per CU to cover the staging loads)
+  const int nseg = (W + UP_SEG - 1) / UP_SEG;
+  const int rb = blockIdx.x / nseg, seg = blockIdx.x - rb * nseg;
   const int r = (HP % 8 == 0) ? (rb & 7) * (HP >> 3) + (rb >> 3) : rb;
   const size_t nb = blockIdx.y;               // n * (Cu/16) + channel block
   const int h = H >> 1, w = W >> 1;
   const float sh = h > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sw = w > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const int ybase = (int)(sh * (float)(2 * r));          // first low-res row needed
-  {   // stage low-res rows ybase .. ybase+2 (clamped): 3 * w * REC halves, 16 bytes per thread and step
+  const int xo0 = seg * UP_SEG, xo1 = min(W, xo0 + UP_SEG);                    // output columns of this segment
+  const int xbase = (int)(sw * (float)xo0);                                     // first low-res column needed
+  const int wseg = min(w - 1, (int)(sw * (float)(xo1 - 1)) + 1) - xbase + 1;    // low-res columns staged
+  {   // stage low-res rows ybase .. ybase+2 (clamped), columns xbase .. xbase+wseg-1: 16 bytes per thread and step
     const half_t* src = low + nb * (size_t)h * w * REC;
-    const int units_row = w * REC / 8;
+    const int units_row = wseg * REC / 8;
     for (int u = threadIdx.x; u < 3 * units_row; u += blockDim.x) {
       const int rr = u / units_row, c = u - rr * units_row;
       const int yy = min(ybase + rr, h - 1);
-      *(u32x4*)(rows + (size_t)u * 8) = *(const u32x4*)(src + ((size_t)yy * w) * REC + (size_t)c * 8);
+      *(u32x4*)(rows + (size_t)u * 8) = *(const u32x4*)(src + ((size_t)yy * w + xbase) * REC + (size_t)c * 8);
     }
   }
   __syncthreads();
-  const int row_items = W * PIECES;           // multiple of 64: every wave is full (DPP exchange below)
+  const int row_items = (xo1 - xo0) * PIECES;  // multiple of 64: every wave is full (DPP exchange below)
   for (int idx = threadIdx.x; idx < 2 * row_items; idx += blockDim.x) {
     const int yo = idx >= row_items;           // which of the two output rows (uniform per wave: 64 | row_items)
     const int id2 = idx - yo * row_items;
@@ -150,13 +158,14 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
     const int piece = id2 & (PIECES - 1);
-    const int x = id2 / PIECES;
+    const int x = xo0 + id2 / PIECES;
     const float fx = sw * (float)x;
-    const int x0 = (int)fx;
-    const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float lx1 = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), lx0 = 1.f - lx1;
-    const half_t* r0 = rows + (size_t)(y0 - ybase) * w * REC;
-    const half_t* r1 = rows + (size_t)(y1 - ybase) * w * REC;
+    const int xg = (int)fx;                     // global low-res column
+    const int x0 = xg - xbase;                  // column inside the staged segment
+    const int x1 = x0 + (xg < w - 1 ? 1 : 0);
+    const float lx1 = fminf(fmaxf(fx - (float)xg, 0.f), 1.f), lx0 = 1.f - lx1;
+    const half_t* r0 = rows + (size_t)(y0 - ybase) * wseg * REC;
+    const half_t* r1 = rows + (size_t)(y1 - ybase) * wseg * REC;
     half_t* dst = out + ((nb * H + y) * W + x) * (size_t)REC + piece * 8;
     if (P == 2) {
       const int oct = piece & 1, role = piece >> 1;       // role 0 stores hi and computes channels 0-3 of the octet
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
       // hi lane: [own channels 0-3 | partner's 4-7]; lo lane: [partner's 0-3 | own 4-7]
       u32x4 o = role ? u32x4{(unsigned)recv[0], (unsigned)recv[1], (unsigned)keep[0], (unsigned)keep[1]}
                      : u32x4{(unsigned)keep[0], (unsigned)keep[1], (unsigned)recv[0], (unsigned)recv[1]};
-      *(u32x4*)dst = o;
+      __builtin_nontemporal_store(o, (u32x4*)dst);     // written once, next read after >1 GB of other traffic
     } else {
       const int e0 = piece * 8;
       half8 a00 = *(const half8*)(r0 + x0 * REC + e0), a01 = *(const half8*)(r0 + x1 * REC + e0);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
         float v = ly0 * (lx0 * (float)a00[e] + lx1 * (float)a01[e]) + ly1 * (lx0 * (float)a10[e] + lx1 * (float)a11[e]);
         rr[e] = (half_t)v;
       }
-      *(half8*)dst = rr;
+      __builtin_nontemporal_store(rr, (half8*)dst);
     }
   }
 }

@@ -661,13 +661,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         const int H = h >> dst.lvl, W = w >> dst.lvl;
         double px = (double)nb * H * W;
         double bytes = px * P * 2.0 * low.C + px / 4 * P * 2.0 * low.C;
-        // enough waves per LDS byte: the staged rows take 3*(W/2)*P*32 bytes per workgroup
-        const int up_threads = (3 * (W / 2) * P * 32 > 32 * 1024) ? 1024 : (3 * (W / 2) * P * 32 > 12 * 1024 ? 512 : 256);
+        const int nseg = (W + UP_SEG - 1) / UP_SEG;
+        const int seg_w = std::min(W, UP_SEG);
+        const size_t up_lds = (size_t)3 * (seg_w / 2 + 2) * P * 32;      // staged low-res rows of one segment
+        const int up_threads = seg_w * 2 * P >= 1024 ? 512 : 256;
         char nm[64];
         snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", dst.lvl, P);
         Lx.run(nm, px * low.C * 8, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 2 * 32, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
-          else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)(H / 2), (unsigned)(nb * (low.C / 16))), dim3(up_threads), 3 * (W / 2) * 1 * 32, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
+          if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
+          else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
           return hipSuccess;
         });
       } else if (op.kind == OP_CONVT) {
