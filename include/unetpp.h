@@ -155,6 +155,28 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
 int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int h, int w, uint32_t* dev_counts,
                       int32_t* dev_row_min, int32_t* dev_row_max, void* stream);
 
+/* ---- frame glue either side of the model --------------------------------
+ * unetpp_resize_linear_u8 replaces `cv2.resize(frame_rgb, target_size, interpolation=cv2.INTER_LINEAR)`
+ * of preprocess_image (infer_two_stage_burr.py:124; also the --normalize-resolution resize, :281):
+ *   dev_src uint8 [B,src_h,src_w,channels] interleaved (channels 1..4)  ->  dev_dst uint8 [B,dst_h,dst_w,channels]
+ * OpenCV's published fixed-point algorithm (11-bit coefficients; see oracle/unetpp_oracle.py
+ * cv2_resize_linear_u8_np — parity unpinned: cv2 is not installable in the build environment).
+ * The result feeds unetpp_forward(_ex) with UNETPP_IN_U8_NHWC_BGR, which does BGR->RGB, /255 and the layout change.
+ *
+ * unetpp_resize_nearest_roi_u8 replaces infer_two_stage_burr.py:303-314 for one class:
+ *   (pred == match_class).astype(uint8)  [match_class < 0: the mask itself]
+ *   -> cv2.resize(mask, (dst_w, dst_h), interpolation=cv2.INTER_NEAREST)
+ *   -> zeros outside rows [y1, y2) x columns [x1, x2) (Python slice semantics for non-negative bounds; pass
+ *      0, 0, dst_w, dst_h for "no ROI").
+ *   dev_src uint8 [B,src_h,src_w]  ->  dev_dst uint8 [B,dst_h,dst_w]
+ * Both are asynchronous on `stream`, except that the first call for a new (source, destination) extent builds
+ * the index tables on the host and uploads them with a blocking copy. */
+int unetpp_resize_linear_u8(unetpp_engine* e, const uint8_t* dev_src, int batch, int src_h, int src_w, int channels,
+                            uint8_t* dev_dst, int dst_h, int dst_w, void* stream);
+int unetpp_resize_nearest_roi_u8(unetpp_engine* e, const uint8_t* dev_src, int batch, int src_h, int src_w,
+                                 int match_class, uint8_t* dev_dst, int dst_h, int dst_w, int x1, int y1, int x2,
+                                 int y2, void* stream);
+
 /* Bytes of device memory held by the engine (workspace + packed weights). */
 size_t unetpp_workspace_bytes(const unetpp_engine* e);
 

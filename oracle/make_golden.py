@@ -218,6 +218,17 @@ def main():
     import json
     with open(os.path.join(OUT, "state_dict_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0)
+
+    # ---- ROI mapping of the frame loop (pure Python in the reference; cv2 only stubbed for the import)
+    import importlib
+    burr = importlib.import_module("infer_two_stage_burr")
+    sizes = [(1920, 1080), (1080, 1920), (1280, 720), (640, 480), (512, 512), (800, 448), (3840, 2160), (1000, 333),
+             (123, 457), (2048, 1536)]
+    roi_cases = [{"size": list(sz), "target": [512, 512], "roi": list(burr.map_roi_to_original(sz, (512, 512)))}
+                 for sz in sizes]
+    roi_cases.append({"size": [1920, 1080], "target": [256, 256], "roi": list(burr.map_roi_to_original((1920, 1080), (256, 256)))})
+    with open(os.path.join(OUT, "roi_map.json"), "w") as f:
+        json.dump({"fixed_roi_512": burr.FIXED_ROI_512, "cases": roi_cases}, f, indent=0)
     with open(os.path.join(OUT, "README.txt"), "w") as f:
         f.write("Golden vectors produced by oracle/make_golden.py from the reference NestedUNet\n"
                 f"(torch {torch.__version__}, {torch.get_num_threads()} threads, CPU fp32) on synthetic weights/frames.\n\n")

@@ -318,6 +318,112 @@ def rule_masks_from_logits(logits_nchw, rule, **params):
     return c, t, probs
 
 
+# ----------------------------------------------------------------------------- frame glue
+# PARITY UNPINNED for the two cv2.resize restatements below: cv2 (opencv-python; the reference pins no version,
+# requirements.txt) is not installed here and the reference holds no resized fixture, so they restate the
+# algorithm OpenCV 4.x publishes in modules/imgproc/src/resize.cpp (generic, non-IPP path) and are only
+# cross-checked against torch's float interpolation (tests/test_oracle_golden.py).  map_roi_to_original and the
+# ROI clip are pinned by the reference's own function (tests/golden/roi_map.json).
+INTER_RESIZE_COEF_BITS = 11
+INTER_RESIZE_COEF_SCALE = 1 << INTER_RESIZE_COEF_BITS
+
+
+def cv2_linear_tables(n_src: int, n_dst: int):
+    """Source index and the two 11-bit fixed-point coefficients per destination index, as resizeGeneric_ builds
+    them for INTER_LINEAR: fx = (float)((d + 0.5) * scale - 0.5) with scale = 1 / (n_dst / n_src) in double,
+    s = floor(fx), clamped at both borders with fx = 0, coefficients saturate_cast<short>(c * 2048) with
+    round-half-to-even."""
+    inv_scale = np.float64(n_dst) / np.float64(n_src)
+    scale = np.float64(1.0) / inv_scale
+    d = np.arange(n_dst, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(fx).astype(np.int32)
+    fx = (fx - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    fx[lo] = 0.0; s[lo] = 0
+    hi = s >= n_src - 1
+    fx[hi] = 0.0; s[hi] = n_src - 1
+    c0 = (np.float32(1.0) - fx).astype(np.float32) * np.float32(INTER_RESIZE_COEF_SCALE)
+    c1 = fx * np.float32(INTER_RESIZE_COEF_SCALE)
+    a0 = np.clip(np.rint(c0), -32768, 32767).astype(np.int32)
+    a1 = np.clip(np.rint(c1), -32768, 32767).astype(np.int32)
+    s1 = np.minimum(s + 1, n_src - 1).astype(np.int32)
+    return s, s1, a0, a1
+
+
+def cv2_resize_linear_u8_np(img: np.ndarray, dsize) -> np.ndarray:
+    """cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_LINEAR) for uint8 [H,W] or [H,W,C]
+    (infer_two_stage_burr.py:124).  Horizontal pass in int32 (src * alpha, scale 2^11), vertical pass
+    ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 — VResizeLinear<uchar,int,short,...>."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    x = np.asarray(img)
+    assert x.dtype == np.uint8
+    sq = x.ndim == 2
+    if sq:
+        x = x[:, :, None]
+    sh, sw = x.shape[:2]
+    xs0, xs1, xa0, xa1 = cv2_linear_tables(sw, dw)
+    ys0, ys1, yb0, yb1 = cv2_linear_tables(sh, dh)
+    xi = x.astype(np.int32)
+    hrow = xi[:, xs0, :] * xa0[None, :, None] + xi[:, xs1, :] * xa1[None, :, None]        # [sh, dw, C]
+    S0 = hrow[ys0] >> 4
+    S1 = hrow[ys1] >> 4
+    out = (((yb0[:, None, None] * S0) >> 16) + ((yb1[:, None, None] * S1) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if sq else out
+
+
+def cv2_nearest_table(n_src: int, n_dst: int):
+    """resizeNN: src = min(floor(d * (1 / (n_dst / n_src))), n_src - 1), all in double."""
+    inv = np.float64(n_dst) / np.float64(n_src)
+    ifx = np.float64(1.0) / inv
+    return np.minimum(np.floor(np.arange(n_dst, dtype=np.float64) * ifx).astype(np.int64), n_src - 1).astype(np.int32)
+
+
+def cv2_resize_nearest_np(img: np.ndarray, dsize) -> np.ndarray:
+    """cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_NEAREST) (infer_two_stage_burr.py:307-308)."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    x = np.asarray(img)
+    return x[cv2_nearest_table(x.shape[0], dh)][:, cv2_nearest_table(x.shape[1], dw)]
+
+
+FIXED_ROI_512 = (140, 0, 270, 512)      # infer_two_stage_burr.py:29-34 (x1, y1, x2, y2)
+
+
+def map_roi_to_original_np(original_size, target_size=(512, 512), roi=FIXED_ROI_512):
+    """infer_two_stage_burr.py:37-47: scale the fixed 512x512 ROI to the frame size, truncating with int()."""
+    ow, oh = original_size
+    tw, th = target_size
+    sx, sy = ow / tw, oh / th
+    return (int(roi[0] * sx), int(roi[1] * sy), int(roi[2] * sx), int(roi[3] * sy))
+
+
+def clip_to_roi_np(mask_full: np.ndarray, roi) -> np.ndarray:
+    """infer_two_stage_burr.py:311-314: zeros outside [y1:y2, x1:x2] (Python slice semantics)."""
+    x1, y1, x2, y2 = roi
+    out = np.zeros_like(mask_full)
+    out[..., y1:y2, x1:x2] = mask_full[..., y1:y2, x1:x2]
+    return out
+
+
+def preprocess_image_np(frame_bgr_u8: np.ndarray, target_size=(512, 512)) -> np.ndarray:
+    """infer_two_stage_burr.py:122-127: BGR->RGB, resize, /255, HWC->CHW (float32 [3,H,W])."""
+    rgb = frame_bgr_u8[..., ::-1]
+    resized = cv2_resize_linear_u8_np(rgb, target_size)
+    return np.ascontiguousarray(np.transpose(resized.astype(np.float32) / np.float32(255.0), (2, 0, 1)))
+
+
+def postprocess_masks_np(pred: np.ndarray, frame_size, roi=None):
+    """infer_two_stage_burr.py:303-314 for one [H,W] class-index mask: class-equality masks, nearest resize to
+    (width, height), ROI clip."""
+    outs = []
+    for cls in (1, 2):
+        m = (pred == cls).astype(np.uint8)
+        full = cv2_resize_nearest_np(m, frame_size)
+        outs.append(clip_to_roi_np(full, roi) if roi is not None else full)
+    return outs[0], outs[1]
+
+
 # ----------------------------------------------------------------------------- torch CPU restatement
 def torch_forward(sd: dict, x, return_intermediates: bool = False):
     """Same graph through torch.nn.functional on the CPU (fp32) — the ops the reference's

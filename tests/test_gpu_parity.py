@@ -370,3 +370,71 @@ def test_engine_reuse_smaller_shapes_and_two_engines(torch_cuda, syn, oracle):
         huge = NestedUNet(3, max_batch=1, max_hw=(8192, 8192)).to("cuda:0")
         huge.load_state_dict(sd)
         huge(torch.zeros(1, 3, 16, 16, device="cuda"))
+
+
+# ---- the cv2.resize steps either side of the model (parity unpinned: cv2 absent; the
+# oracle restates OpenCV's published fixed-point INTER_LINEAR / INTER_NEAREST, the device must match it bit for bit)
+@pytest.mark.parametrize("shape,dsize", [((2, 1080, 1920, 3), (512, 512)), ((1, 480, 640, 3), (800, 448)),
+                                         ((3, 37, 53, 1), (16, 16)), ((1, 64, 48, 3), (48, 64)),
+                                         ((2, 5, 7, 3), (31, 13)), ((1, 720, 1280, 4), (510, 254))])
+def test_resize_linear_matches_cv2_restatement(shape, dsize, torch_cuda, syn, oracle):
+    torch = torch_cuda
+    rng = np.random.default_rng(shape[1] * 7 + shape[2])
+    frames = rng.integers(0, 256, shape, dtype=np.uint8)
+    model, _ = make_model(3, True, 2, "exact", syn, 1, (16, 16))
+    got = model.resize_frames(torch.from_numpy(frames).cuda(), (dsize[1], dsize[0]))
+    torch.cuda.synchronize()
+    assert got.shape == (shape[0], dsize[1], dsize[0], shape[3])
+    for b in range(shape[0]):
+        ref = oracle.cv2_resize_linear_u8_np(frames[b], dsize)
+        assert np.array_equal(got[b].cpu().numpy(), ref.reshape(dsize[1], dsize[0], shape[3])), f"frame {b}"
+
+
+@pytest.mark.parametrize("src_hw,frame_wh,roi", [((512, 512), (1920, 1080), (525, 0, 1012, 1080)),
+                                                  ((512, 512), (1080, 1920), None),
+                                                  ((64, 96), (333, 127), (10, 5, 400, 90)),
+                                                  ((48, 80), (80, 48), (0, 0, 0, 0)),
+                                                  ((128, 128), (50, 30), (7, 3, 8, 4))])
+def test_resize_nearest_roi_matches_restatement(src_hw, frame_wh, roi, torch_cuda, syn, oracle):
+    torch = torch_cuda
+    rng = np.random.default_rng(src_hw[0] + frame_wh[0])
+    pred = rng.integers(0, 3, (2,) + src_hw, dtype=np.uint8)
+    model, _ = make_model(3, True, 2, "exact", syn, 1, (16, 16))
+    d = torch.from_numpy(pred).cuda()
+    for cls in (-1, 1, 2):
+        got = model.resize_masks(d, frame_wh, match_class=cls, roi=roi).cpu().numpy()
+        for b in range(2):
+            m = pred[b] if cls < 0 else (pred[b] == cls).astype(np.uint8)
+            ref = oracle.cv2_resize_nearest_np(m, frame_wh)
+            if roi is not None:
+                ref = oracle.clip_to_roi_np(ref, roi)
+            assert np.array_equal(got[b], ref), (cls, b)
+    with pytest.raises(RuntimeError, match="negative ROI"):
+        model.resize_masks(d, frame_wh, roi=(-1, 0, 5, 5))
+
+
+def test_process_frames_whole_loop_on_device(torch_cuda, syn, oracle):
+    """Raw BGR frames -> resize -> model -> argmax -> class masks at frame size inside the ROI, against the same
+    chain on the CPU (oracle preprocess_image_np -> torch_segment -> postprocess_masks_np)."""
+    torch = torch_cuda
+    from unet_amd.frame_loop import process_frames, map_roi_to_original
+    fh, fw, th, tw = 270, 480, 96, 128
+    frames = syn.make_frames_u8(3, fh, fw, "smooth", 40)
+    model, sd = make_model(3, True, 2, "exact", syn, 3, (th, tw))
+    pred, cable, tape = process_frames(model, frames, target_size=(tw, th), roi="fixed")
+    torch.cuda.synchronize()
+    roi = map_roi_to_original((fw, fh), (tw, th))
+    assert cable.shape == (3, fh, fw) and tape.shape == (3, fh, fw)
+    for b in range(3):
+        x = oracle.preprocess_image_np(frames[b], (tw, th))[None]
+        ref_logits = oracle.torch_forward(sd, x)
+        ref_pred = oracle.masks_from_logits(ref_logits)[0][0]          # [H,W]
+        got_pred = pred[b].cpu().numpy()
+        flips = got_pred != ref_pred
+        assert not (flips & (oracle.top2_margin(ref_logits)[0] > 1e-4)).any()
+        # the glue after the model is integer work: exact given the device's own pred
+        rc, rt = oracle.postprocess_masks_np(got_pred, (fw, fh), roi)
+        assert np.array_equal(cable[b].cpu().numpy(), rc) and np.array_equal(tape[b].cpu().numpy(), rt)
+        if not flips.any():
+            rc2, rt2 = oracle.postprocess_masks_np(ref_pred, (fw, fh), roi)
+            assert np.array_equal(cable[b].cpu().numpy(), rc2) and np.array_equal(tape[b].cpu().numpy(), rt2)

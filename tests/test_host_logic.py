@@ -15,7 +15,7 @@ def test_library_builds_and_exports_all_symbols():
     path = _lib.build()
     lib = ctypes.CDLL(path)
     header = open(os.path.join(ROOT, "include", "unetpp.h")).read()
-    declared = set(re.findall(r"\b(unetpp_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(unetpp_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym

@@ -171,3 +171,60 @@ def test_simple_unet_manifest_and_blob(syn):
     assert blob[:32].view(np.uint32)[5] == 1
     with pytest.raises(RuntimeError, match="Missing key"):
         bad = dict(sd); bad.pop("up2.bias"); packing.check_simple_state_dict(bad, 7)
+
+
+# ---- frame glue ------------------------------------------------------------------------
+def test_roi_mapping_matches_reference_function(oracle):
+    """map_roi_to_original (infer_two_stage_burr.py:37-47): oracle restatement and the host mirror against
+    values the reference's own function returned (tests/golden/roi_map.json)."""
+    import json
+    from unet_amd import frame_loop
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "roi_map.json")))
+    assert g["fixed_roi_512"] == frame_loop.FIXED_ROI_512
+    assert tuple(g["fixed_roi_512"][k] for k in ("x1", "y1", "x2", "y2")) == oracle.FIXED_ROI_512
+    for c in g["cases"]:
+        assert list(oracle.map_roi_to_original_np(tuple(c["size"]), tuple(c["target"]))) == c["roi"]
+        assert list(frame_loop.map_roi_to_original(tuple(c["size"]), tuple(c["target"]))) == c["roi"]
+
+
+def test_cv2_linear_restatement_properties(oracle):
+    """PARITY UNPINNED (cv2 absent): the INTER_LINEAR restatement is checked for the properties OpenCV's
+    fixed-point algorithm has and against torch's float bilinear (same half-pixel geometry) to 1 LSB."""
+    import torch
+    rng = np.random.default_rng(5)
+    for (sh, sw, c), (dw, dh) in [((108, 192, 3), (64, 64)), ((40, 30, 1), (90, 70)), ((33, 77, 3), (77, 33))]:
+        img = rng.integers(0, 256, (sh, sw, c), dtype=np.uint8)
+        out = oracle.cv2_resize_linear_u8_np(img, (dw, dh))
+        assert out.shape == (dh, dw, c) and out.dtype == np.uint8
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+        ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(out.astype(np.float32) - ref).max() < 1.0
+    img = rng.integers(0, 256, (21, 17, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.cv2_resize_linear_u8_np(img, (17, 21)), img)            # same size = identity
+    flat = np.full((9, 11), 201, np.uint8)
+    assert np.all(oracle.cv2_resize_linear_u8_np(flat, (40, 23)) == 201)                 # constants survive
+    s0, s1, a0, a1 = oracle.cv2_linear_tables(1920, 512)
+    assert np.all(a0 + a1 == 2048) and s0.min() >= 0 and s1.max() <= 1919 and np.all(s1 - s0 <= 1)
+    # worked example, 2 -> 4 samples: fx = -0.25, 0.25, 0.75, 1.25 -> (s, a1) = (0, 0), (0, 512), (0, 1536), (1, 0)
+    s0, s1, a0, a1 = oracle.cv2_linear_tables(2, 4)
+    assert s0.tolist() == [0, 0, 0, 1] and a1.tolist() == [0, 512, 1536, 0]
+    row = np.array([[0, 255]], np.uint8)
+    assert oracle.cv2_resize_linear_u8_np(row, (4, 1)).tolist() == [[0, 64, 191, 255]]
+
+
+def test_cv2_nearest_restatement_and_roi_clip(oracle):
+    """INTER_NEAREST = floor(dst * src/dst) (torch documents its mode='nearest' as matching OpenCV's
+    INTER_NEAREST); ROI clip = Python slice semantics (infer_two_stage_burr.py:311-314)."""
+    import torch
+    rng = np.random.default_rng(6)
+    for (sh, sw), (dw, dh) in [((512, 512), (1920, 1080)), ((64, 96), (333, 127)), ((128, 128), (50, 30))]:
+        m = rng.integers(0, 3, (sh, sw), dtype=np.uint8)
+        out = oracle.cv2_resize_nearest_np(m, (dw, dh))
+        ref = torch.nn.functional.interpolate(torch.from_numpy(m)[None, None].float(), size=(dh, dw), mode="nearest")
+        assert np.array_equal(out, ref[0, 0].numpy().astype(np.uint8))
+    full = np.ones((30, 40), np.uint8)
+    c = oracle.clip_to_roi_np(full, (5, 2, 100, 7))
+    assert c.sum() == 35 * 5 and c[2:7, 5:].all() and not c[:2].any()
+    cable, tape = oracle.postprocess_masks_np(np.array([[0, 1], [2, 1]], np.uint8), (4, 4), (0, 0, 4, 2))
+    assert cable.tolist() == [[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]]
+    assert tape.tolist() == [[0] * 4] * 4

@@ -19,6 +19,7 @@ ABI_SYMBOLS = [
     "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
     "unetpp_weights_blob_bytes_arch",
     "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_forward_ex", "unetpp_mask_stats", "unetpp_workspace_bytes",
+    "unetpp_resize_linear_u8", "unetpp_resize_nearest_roi_u8",
     "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
     "unetpp_profile_work", "unetpp_debug_read", "unetpp_debug_keep_intermediates",
 ]
@@ -89,6 +90,9 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_forward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]; lib.unetpp_forward.restype = ci
     lib.unetpp_forward_ex.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(Outputs), vp]; lib.unetpp_forward_ex.restype = ci
     lib.unetpp_mask_stats.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp]; lib.unetpp_mask_stats.restype = ci
+    lib.unetpp_resize_linear_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp]; lib.unetpp_resize_linear_u8.restype = ci
+    lib.unetpp_resize_nearest_roi_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
+    lib.unetpp_resize_nearest_roi_u8.restype = ci
     lib.unetpp_workspace_bytes.argtypes = [vp]; lib.unetpp_workspace_bytes.restype = cs
     lib.unetpp_profile_enable.argtypes = [vp, ci]; lib.unetpp_profile_enable.restype = ci
     lib.unetpp_profile_count.argtypes = [vp]; lib.unetpp_profile_count.restype = ci

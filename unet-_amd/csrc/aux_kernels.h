@@ -283,6 +283,69 @@ __global__ void head_generic_kernel(const half_t* __restrict__ x, int Cx, const 
   if (tape) tape[o] = is_tape;
 }
 
+// ---- frame glue: cv2.resize either side of the model ----------------------------------
+// Both kernels take per-axis tables the host builds the way OpenCV's resizeGeneric_/resizeNN do (double/float
+// index math, 11-bit fixed-point coefficients), so the device side is integer-only.
+//   lin table entry {s0, s1, a0, a1}: out = s0-th and s1-th source sample weighted a0, a1 (a0 + a1 = 2048)
+// resize_linear_u8_kernel: cv2.resize(frame, (dw, dh), INTER_LINEAR) for B interleaved C-channel uint8 frames
+// (infer_two_stage_burr.py:124).  Horizontal pass in int32, vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+// grid = (ceil(dw*C / (4*256)), dh, B); a thread produces 4 consecutive output bytes.
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int C,
+                                                               uint8_t* __restrict__ dst, int dh, int dw,
+                                                               const int4* __restrict__ xtab, const int4* __restrict__ ytab) {
+  const int row_bytes = dw * C;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= row_bytes) return;
+  const int dy = blockIdx.y;
+  const int4 yt = ytab[dy];
+  const uint8_t* r0 = src + ((size_t)blockIdx.z * sh + yt.x) * (size_t)sw * C;
+  const uint8_t* r1 = src + ((size_t)blockIdx.z * sh + yt.y) * (size_t)sw * C;
+  uint8_t* o = dst + ((size_t)blockIdx.z * dh + dy) * (size_t)row_bytes + i0;
+  uint32_t packed = 0;
+  const int n = min(4, row_bytes - i0);
+  for (int j = 0; j < n; ++j) {
+    const int i = i0 + j;
+    const int dx = i / C, c = i - dx * C;
+    const int4 xt = xtab[dx];
+    const int S0 = (int)r0[xt.x * C + c] * xt.z + (int)r0[xt.y * C + c] * xt.w;
+    const int S1 = (int)r1[xt.x * C + c] * xt.z + (int)r1[xt.y * C + c] * xt.w;
+    int v = (((yt.z * (S0 >> 4)) >> 16) + ((yt.w * (S1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    packed |= (uint32_t)v << (8 * j);
+  }
+  if (n == 4 && (row_bytes & 3) == 0) *(uint32_t*)o = packed;
+  else for (int j = 0; j < n; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+}
+
+// resize_nearest_roi_u8_kernel: (pred == match_class) [or the mask itself when match_class < 0], cv2.resize(...,
+// (dw, dh), INTER_NEAREST), then zero outside rows [y1, y2) x columns [x1, x2) — infer_two_stage_burr.py:303-314.
+// xofs/yofs: source index per destination column/row.  grid = (ceil(dw / (4*256)), dh, B).
+__global__ __launch_bounds__(256) void resize_nearest_roi_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw,
+                                                                    uint8_t* __restrict__ dst, int dh, int dw,
+                                                                    const int* __restrict__ xofs, const int* __restrict__ yofs,
+                                                                    int match_class, int x1, int y1, int x2, int y2) {
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= dw) return;
+  const int dy = blockIdx.y;
+  const bool row_in = dy >= y1 && dy < y2;
+  const uint8_t* r = src + ((size_t)blockIdx.z * sh + yofs[dy]) * (size_t)sw;
+  uint8_t* o = dst + ((size_t)blockIdx.z * dh + dy) * (size_t)dw + i0;
+  uint32_t packed = 0;
+  const int n = min(4, dw - i0);
+  for (int j = 0; j < n; ++j) {
+    const int dx = i0 + j;
+    uint32_t v = 0;
+    if (row_in && dx >= x1 && dx < x2) {
+      v = r[xofs[dx]];
+      if (match_class >= 0) v = v == (uint32_t)match_class ? 1u : 0u;
+    }
+    packed |= v << (8 * j);
+  }
+  if (n == 4 && (dw & 3) == 0) *(uint32_t*)o = packed;
+  else for (int j = 0; j < n; ++j) o[j] = (uint8_t)(packed >> (8 * j));
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Per-frame mask statistics so that the uint8 mask need not leave the GPU when the
 // host only wants counts and widths:

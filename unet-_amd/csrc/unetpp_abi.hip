@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "../../include/unetpp.h"
@@ -120,6 +122,8 @@ struct unetpp_engine {
   size_t last_slot_off = 0;
   hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  // frame glue: per-axis resize tables on the device, keyed by (kind, n_src, n_dst); kind 0 = linear, 1 = nearest
+  std::map<std::tuple<int, int, int>, void*> resize_tabs;
 };
 
 namespace {
@@ -496,6 +500,7 @@ void unetpp_destroy(unetpp_engine* e) {
   for (int i = 0; i < 4; ++i) { if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]); if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]); }
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
   if (e->arena) (void)hipFree(e->arena);
+  for (auto& kv : e->resize_tabs) (void)hipFree(kv.second);
   delete e;
 }
 
@@ -725,6 +730,95 @@ int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int 
   HIP_TRY(e, hipMemsetAsync(dev_counts, 0, (size_t)batch * C * sizeof(uint32_t), s));
   hipLaunchKernelGGL(mask_stats_kernel, dim3((unsigned)h, (unsigned)batch), dim3(256), 0, s, dev_mask, C, h, w,
                      (unsigned*)dev_counts, (int*)dev_row_min, (int*)dev_row_max);
+  HIP_TRY(e, hipGetLastError());
+  return UNETPP_OK;
+}
+
+// ---- frame glue: cv2.resize either side of the model ----------------------------------
+}  // extern "C"
+namespace {
+// resizeGeneric_'s INTER_LINEAR index/coefficient tables (OpenCV imgproc/src/resize.cpp): double index math, float
+// fraction, saturate_cast<short>(c * 2048) with round-half-even.  Entry = {s0, s1, a0, a1}.
+void linear_table(int n_src, int n_dst, std::vector<int>& t) {
+#pragma clang fp contract(off)
+  t.resize((size_t)n_dst * 4);
+  const double inv_scale = (double)n_dst / (double)n_src;
+  const double scale = 1.0 / inv_scale;
+  for (int d = 0; d < n_dst; ++d) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int s0 = (int)floorf(fx);
+    fx -= (float)s0;
+    if (s0 < 0) { fx = 0.f; s0 = 0; }
+    if (s0 >= n_src - 1) { fx = 0.f; s0 = n_src - 1; }
+    const float c0 = (1.f - fx) * 2048.f, c1 = fx * 2048.f;
+    long a0 = lrintf(c0), a1 = lrintf(c1);
+    a0 = std::min(32767L, std::max(-32768L, a0));
+    a1 = std::min(32767L, std::max(-32768L, a1));
+    t[4 * d + 0] = s0; t[4 * d + 1] = std::min(s0 + 1, n_src - 1); t[4 * d + 2] = (int)a0; t[4 * d + 3] = (int)a1;
+  }
+}
+// resizeNN's index table: min(floor(d * (1 / (n_dst / n_src))), n_src - 1) in double.
+void nearest_table(int n_src, int n_dst, std::vector<int>& t) {
+#pragma clang fp contract(off)
+  t.resize((size_t)n_dst);
+  const double inv = (double)n_dst / (double)n_src;
+  const double ifx = 1.0 / inv;
+  for (int d = 0; d < n_dst; ++d) t[d] = std::min((int)floor(d * ifx), n_src - 1);
+}
+// Device copy of a table, built on first use (that first call synchronises: a blocking hipMemcpy).
+int resize_table(unetpp_engine* e, int kind, int n_src, int n_dst, void** out) {
+  auto key = std::make_tuple(kind, n_src, n_dst);
+  auto it = e->resize_tabs.find(key);
+  if (it == e->resize_tabs.end()) {
+    std::vector<int> t;
+    if (kind == 0) linear_table(n_src, n_dst, t); else nearest_table(n_src, n_dst, t);
+    void* d = nullptr;
+    HIP_TRY(e, hipMalloc(&d, t.size() * sizeof(int)));
+    hipError_t r = hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (r != hipSuccess) { (void)hipFree(d); return fail(e, UNETPP_E_HIP, "hipMemcpy(resize table): %s", hipGetErrorString(r)); }
+    it = e->resize_tabs.emplace(key, d).first;
+  }
+  *out = it->second;
+  return UNETPP_OK;
+}
+}  // namespace
+extern "C" {
+
+int unetpp_resize_linear_u8(unetpp_engine* e, const uint8_t* dev_src, int batch, int src_h, int src_w, int channels,
+                            uint8_t* dev_dst, int dst_h, int dst_w, void* stream) {
+  if (!e) return UNETPP_E_INVALID;
+  if (!dev_src || !dev_dst) return fail(e, UNETPP_E_INVALID, "null argument");
+  if (batch < 1 || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || channels < 1 || channels > 4)
+    return fail(e, UNETPP_E_INVALID, "bad resize shape %dx%dx%dx%d -> %dx%d", batch, src_h, src_w, channels, dst_h, dst_w);
+  if (batch > 65535 || dst_h > 65535 || (size_t)src_h * src_w * channels > 0x7fffffffULL)
+    return fail(e, UNETPP_E_INVALID, "resize shape too large");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  void *xt = nullptr, *yt = nullptr;
+  int rc = resize_table(e, 0, src_w, dst_w, &xt); if (rc) return rc;
+  rc = resize_table(e, 0, src_h, dst_h, &yt); if (rc) return rc;
+  const unsigned gx = (unsigned)((dst_w * channels + 1023) / 1024);
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3(gx, (unsigned)dst_h, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     dev_src, src_h, src_w, channels, dev_dst, dst_h, dst_w, (const int4*)xt, (const int4*)yt);
+  HIP_TRY(e, hipGetLastError());
+  return UNETPP_OK;
+}
+
+int unetpp_resize_nearest_roi_u8(unetpp_engine* e, const uint8_t* dev_src, int batch, int src_h, int src_w, int match_class,
+                                 uint8_t* dev_dst, int dst_h, int dst_w, int x1, int y1, int x2, int y2, void* stream) {
+  if (!e) return UNETPP_E_INVALID;
+  if (!dev_src || !dev_dst) return fail(e, UNETPP_E_INVALID, "null argument");
+  if (batch < 1 || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1)
+    return fail(e, UNETPP_E_INVALID, "bad resize shape %dx%dx%d -> %dx%d", batch, src_h, src_w, dst_h, dst_w);
+  if (batch > 65535 || dst_h > 65535) return fail(e, UNETPP_E_INVALID, "resize shape too large");
+  if (x1 < 0 || y1 < 0 || x2 < 0 || y2 < 0) return fail(e, UNETPP_E_INVALID, "negative ROI bound (%d, %d, %d, %d)", x1, y1, x2, y2);
+  if (match_class > 255) return fail(e, UNETPP_E_INVALID, "match_class %d out of range", match_class);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  void *xo = nullptr, *yo = nullptr;
+  int rc = resize_table(e, 1, src_w, dst_w, &xo); if (rc) return rc;
+  rc = resize_table(e, 1, src_h, dst_h, &yo); if (rc) return rc;
+  const unsigned gx = (unsigned)((dst_w + 1023) / 1024);
+  hipLaunchKernelGGL(resize_nearest_roi_u8_kernel, dim3(gx, (unsigned)dst_h, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     dev_src, src_h, src_w, dev_dst, dst_h, dst_w, (const int*)xo, (const int*)yo, match_class, x1, y1, x2, y2);
   HIP_TRY(e, hipGetLastError());
   return UNETPP_OK;
 }

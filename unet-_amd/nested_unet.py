@@ -246,6 +246,46 @@ class NestedUNet:
         widths = torch.where(rmax >= 0, (rmax - rmin + 1), torch.zeros_like(rmax)).to(torch.float32)
         return counts.to(torch.int64), widths
 
+    def resize_frames(self, frames, size_hw):
+        """cv2.resize(frame, (W, H), interpolation=cv2.INTER_LINEAR) for uint8 CUDA frames [B,h,w,C] -> [B,H,W,C]
+        (preprocess_image, infer_two_stage_burr.py:124).  Chain with segment(): the BGR->RGB swap and /255 run
+        inside the engine's first kernel."""
+        import torch
+        if not (isinstance(frames, torch.Tensor) and frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4):
+            raise RuntimeError("frames must be a uint8 CUDA tensor [B,H,W,C]")
+        H, W = int(size_hw[0]), int(size_hw[1])
+        self._ensure_engine(1, self._SIZE_MULTIPLE, self._SIZE_MULTIPLE)
+        frames = frames.contiguous()
+        b, h, w, c = frames.shape
+        out = torch.empty((b, H, W, c), dtype=torch.uint8, device=frames.device)
+        rc = _lib.load().unetpp_resize_linear_u8(self._handle, ctypes.c_void_p(frames.data_ptr()), b, h, w, c,
+                                                 ctypes.c_void_p(out.data_ptr()), H, W,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        return out
+
+    def resize_masks(self, pred, frame_size_wh, match_class: int = -1, roi=None):
+        """infer_two_stage_burr.py:303-314 on the device for a uint8 CUDA mask [B,H,W]: optional
+        `(pred == match_class)`, cv2.resize(..., (width, height), INTER_NEAREST), zeros outside
+        roi = (x1, y1, x2, y2).  Returns uint8 [B,height,width]."""
+        import torch
+        if not (isinstance(pred, torch.Tensor) and pred.is_cuda and pred.dtype == torch.uint8 and pred.dim() == 3):
+            raise RuntimeError("pred must be a uint8 CUDA tensor [B,H,W]")
+        fw, fh = int(frame_size_wh[0]), int(frame_size_wh[1])
+        x1, y1, x2, y2 = (0, 0, fw, fh) if roi is None else (int(v) for v in roi)
+        self._ensure_engine(1, self._SIZE_MULTIPLE, self._SIZE_MULTIPLE)
+        pred = pred.contiguous()
+        b, h, w = pred.shape
+        out = torch.empty((b, fh, fw), dtype=torch.uint8, device=pred.device)
+        rc = _lib.load().unetpp_resize_nearest_roi_u8(self._handle, ctypes.c_void_p(pred.data_ptr()), b, h, w,
+                                                      int(match_class), ctypes.c_void_p(out.data_ptr()), fh, fw,
+                                                      x1, y1, x2, y2,
+                                                      ctypes.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        return out
+
     def predict_proba(self, x):
         """softmax(model(x), dim=1) as float32 [B,C,H,W] on the device (one fused pass)."""
         return self._run(x, False, False, False, True)[4]
