@@ -58,11 +58,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + \
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"      # several ranks may build at once: write aside, then rename atomically
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(cmd).replace(tmp, LIB_PATH), flush=True)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
