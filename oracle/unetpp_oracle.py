@@ -164,6 +164,8 @@ def masks_from_logits(logits: np.ndarray):
 
 def top2_margin(logits: np.ndarray) -> np.ndarray:
     """Per-pixel gap between the largest and second-largest logit (for margin-aware flip accounting)."""
+    if logits.shape[1] < 2:                     # a single class cannot flip
+        return np.full(logits.shape[:1] + logits.shape[2:], np.inf, np.float32)
     s = np.sort(logits, axis=1)
     return (s[:, -1] - s[:, -2]).astype(np.float32)
 
