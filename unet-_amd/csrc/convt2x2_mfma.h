@@ -4,7 +4,8 @@
 // = a 1x1 convolution with 4*Cout "virtual channels" v = (dy*2+dx)*Cout + co followed by a pixel shuffle
 // that the epilogue does while storing.  It is ~4 % of SimpleUNet's FLOPs, so the kernel is deliberately
 // simple: no LDS, no barriers; every wave owns a 128-pixel x 64-virtual-channel tile (8 accumulators)
-// and streams its MFMA operands straight from global memory / L2 (12 x 1 KiB loads per 24 MFMAs).
+// and streams its MFMA operands straight from global memory / L2 (12 x 1 KiB loads per 24 MFMAs, register
+// double-buffered one K-step ahead).
 // Same operand conventions as conv3x3_mfma.h: weights are the A operand (virtual channel on the row),
 // pixels the B operand (pixel on the lane); EXACT mode (P = 2) issues lo*hi, hi*lo, hi*hi.
 #pragma once
@@ -22,14 +23,24 @@ struct ConvTArgs {
 };
 
 template <int P>
-__global__ __launch_bounds__(256) void convt2x2_kernel(ConvTArgs a) {
+__global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int HW = a.H * a.W;
-  const int n = blockIdx.z;
-  const int pbase = (blockIdx.x * 4 + wave) * 128;           // first flattened pixel of this wave's tile
+  // 1-D grid = N * pixel tiles (512 px) * virtual-channel groups (64 wide).  Workgroups b, b+8, ... share an XCD
+  // (round-robin dispatch): give each XCD a contiguous run of work ids with the channel group fastest, so the
+  // 4*Cout/64 workgroups that re-read one pixel tile find it in their own L2.  Speed only.
+  const int nvg = (4 * a.Cout) >> 6;
+  const int ptiles = (HW + 511) >> 9;
+  const int G = (int)gridDim.x;
+  const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int vg = slot % nvg;
+  const int pt_n = slot / nvg;
+  const int ptile = pt_n % ptiles;
+  const int n = pt_n / ptiles;
+  const int pbase = (ptile * 4 + wave) * 128;                 // first flattened pixel of this wave's tile
   if (pbase >= HW) return;                                    // whole wave out of range (no barriers in this kernel)
-  const int vt0 = blockIdx.y * 2;                             // first 32-wide virtual-channel tile
+  const int vt0 = vg * 2;                                     // first 32-wide virtual-channel tile
   const int K16 = a.Cin >> 4;
   const int h = lane >> 5;
 
@@ -46,31 +57,49 @@ __global__ __launch_bounds__(256) void convt2x2_kernel(ConvTArgs a) {
   for (int pt = 0; pt < 4; ++pt) pix[pt] = min(pbase + pt * 32 + (lane & 31), HW - 1);   // clamp: discarded at the store
   const half_t* in_n = a.in + (size_t)n * a.Cin * HW * P;
 
-  for (int kk = 0; kk < K16; ++kk) {
-    half8 wh[2], wl[2], xh[4], xl[4];
+  // operands of one K-step (16 input channels): 12 x 16-byte loads per lane in exact mode.  Two register sets:
+  // the loads of step kk+1 are in flight under the 24 MFMAs of step kk.
+  struct Ops { half8 wh[2], wl[2], xh[4], xl[4]; };
+  auto load_ops = [&](Ops& o, int kk) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const half_t* w = a.wpk + (((size_t)(vt0 + j) * K16 + kk) * P) * 512 + lane * 8;
-      wh[j] = *(const half8*)w;
-      if (P == 2) wl[j] = *(const half8*)(w + 512);
+      o.wh[j] = *(const half8*)w;
+      if (P == 2) o.wl[j] = *(const half8*)(w + 512);
     }
     const half_t* blk = in_n + (size_t)kk * HW * (P * 16) + h * 8;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const half_t* x = blk + (size_t)pix[pt] * (P * 16);
-      xh[pt] = *(const half8*)x;
-      if (P == 2) xl[pt] = *(const half8*)(x + 16);
+      o.xh[pt] = *(const half8*)x;
+      if (P == 2) o.xl[pt] = *(const half8*)(x + 16);
     }
+  };
+  auto run_mfma = [&](const Ops& o) {
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (P == 2) {
-          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[pt], acc[pt][j], 0, 0, 0);
-          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[pt], acc[pt][j], 0, 0, 0);
+          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh[j], o.xl[pt], acc[pt][j], 0, 0, 0);
+          acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl[j], o.xh[pt], acc[pt][j], 0, 0, 0);
         }
-        acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[pt], acc[pt][j], 0, 0, 0);
+        acc[pt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh[j], o.xh[pt], acc[pt][j], 0, 0, 0);
       }
+  };
+  Ops o0, o1;
+  load_ops(o0, 0);
+  for (int kk = 0; kk < K16; kk += 2) {
+    if (kk + 1 < K16) load_ops(o1, kk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    run_mfma(o0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kk + 1 < K16) {
+      if (kk + 2 < K16) load_ops(o0, kk + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      run_mfma(o1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue: scale, bias (no activation), pixel shuffle, fp16 hi/lo packing, 16-byte stores

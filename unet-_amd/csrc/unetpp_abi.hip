@@ -686,7 +686,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         double px = (double)nb * H * W;
         double flops = 2.0 * px * T.cin * T.cout * 4;
         double bytes = px * P * 2.0 * (T.cin + 4.0 * T.cout) + 4.0 * T.cin * T.cout * 2.0 * P;
-        dim3 grid((unsigned)((H * W + 511) / 512), (unsigned)(4 * T.cout / 64), (unsigned)nb);
+        dim3 grid((unsigned)(((H * W + 511) / 512) * (4 * T.cout / 64) * nb));
         char lbl[96];
         snprintf(lbl, sizeof lbl, "%s|convt2x2_kernel<%d>", T.name.c_str(), P);
         Lx.run(lbl, flops, bytes, [&] {
