@@ -141,11 +141,11 @@ def make_frame_u8(h: int, w: int, index: int = 0, kind: str = "smooth", seed: in
     lo = rng.uniform(0.0, 255.0, (max(h // 32, 2), max(w // 32, 2), 3))
     noise = rng.uniform(0.0, 255.0, (h, w, 3))
     f = 0.8 * _bilinear_up(lo, h, w) + 0.2 * noise
-    return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(np.rint(f), 0, 255).astype(np.uint8))     # C order: raw memcpy-able
 
 
 def make_frames_u8(b: int, h: int, w: int, kind: str = "smooth", seed: int = 1234, first: int = 0) -> np.ndarray:
-    return np.stack([make_frame_u8(h, w, first + i, kind, seed) for i in range(b)])
+    return np.ascontiguousarray(np.stack([make_frame_u8(h, w, first + i, kind, seed) for i in range(b)]))
 
 
 def frames_to_chw_f32(frames_u8: np.ndarray) -> np.ndarray:
