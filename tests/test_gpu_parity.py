@@ -440,3 +440,41 @@ def test_process_frames_whole_loop_on_device(torch_cuda, syn, oracle):
         if not flips.any():
             rc2, rt2 = oracle.postprocess_masks_np(ref_pred, (fw, fh), roi)
             assert np.array_equal(cable[b].cpu().numpy(), rc2) and np.array_equal(tape[b].cpu().numpy(), rt2)
+
+
+def test_determinism_side_stream_and_threads(torch_cuda, syn):
+    """Same input -> bitwise the same logits: run to run, on a non-default stream, and from two host threads
+    driving two independent engines at once (include/unetpp.h: an engine is not thread-safe, independent engines are)."""
+    import threading
+    torch = torch_cuda
+    B, H, W = 3, 96, 160
+    frames = syn.make_frames_u8(B, H, W, "smooth", 9)
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    m1, _ = make_model(3, True, 2, "exact", syn, B, (H, W))
+    m2, _ = make_model(3, True, 2, "exact", syn, B, (H, W))
+    a = m1(x)
+    b = m1(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = m1(x)
+        mask_side = m1.segment(x)
+    side.synchronize()
+    assert torch.equal(a, c) and torch.equal(mask_side, a.argmax(1).to(torch.uint8))
+    results = {}
+
+    def worker(name, model):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            outs = [model(x) for _ in range(5)]
+        s.synchronize()
+        results[name] = outs
+    ts = [threading.Thread(target=worker, args=(n, m)) for n, m in (("m1", m1), ("m2", m2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for outs in results.values():
+        assert len(outs) == 5 and all(torch.equal(o, a) for o in outs)
