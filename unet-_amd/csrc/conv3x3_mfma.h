@@ -11,10 +11,11 @@
 //       TH = WAVES*MW rows, every wave owns MW rows x all BN channels
 //   N = BN = 32*NW output channels,  K = 9 taps x Cin, walked in chunks of KC input channels.
 // Per chunk the workgroup holds in LDS (double buffered, one barrier per chunk):
-//   * the input halo  (TH+2) x 34 pixels x KC channels — loaded to registers while the previous chunk
-//     computes (bounds / zero padding handled there), written to the other buffer afterwards;
+//   * the input halo  (TH+2) x 34 pixels x KC channels — buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds)
+//     straight from HBM/L2 while the previous chunk computes; pixels outside the image carry an out-of-range
+//     buffer offset and arrive as zeros (the convolution's padding), no registers or ds_write in between;
 //   * the weight slab 9 x KC x BN — pre-packed in exactly the order the B fragments are read, so it is
-//     a linear copy done by LDS-DMA (global_load_lds_dwordx4), in flight during the MFMAs.
+//     a linear copy, also by LDS-DMA (global_load_lds_dwordx4), in flight during the MFMAs.
 // Activation layout in HBM: channel-blocked NHWC, [N][C/16][H][W][P][16] fp16 (block of CB = min(16, C)
 // channels; P = 1 (FAST) or 2 (EXACT: plane 0 = hi, plane 1 = lo, value = hi + lo)).  One K-chunk of 16
 // channels is therefore one contiguous 32*P bytes per pixel and consecutive pixels are contiguous: a halo
@@ -23,9 +24,9 @@
 // EXACT issues three MFMAs per product (lo*hi, hi*lo, hi*hi) into one fp32 accumulator.
 //
 // LDS images (bytes):
-//   halo   [P][KG=KC/8][halo pixel][8 halves]  plane stride KGS == 32 (mod 128): the 8-lane groups of
-//          ds_write_b128 (2 pixels x 4 channel groups) hit distinct banks; the A-fragment ds_read_b128 of
-//          a 32x16 tile reads 2 x 512 contiguous bytes -> conflict-free.
+//   halo   1 KiB pieces (one DMA wave-instruction each) of [unit][PPP pixels][8 halves], unit = plane*KG +
+//          k-group, PPP = 64 / (P*KG) consecutive halo pixels; the A-fragment ds_read_b128 of a 32x16 tile
+//          reads contiguous runs of PPP*16 bytes -> conflict-free.
 //   slab   [P][tap][KG][BN][8 halves]           B-fragment read = 2 x 512 contiguous bytes.
 // Workgroups are persistent: each walks tiles blockIdx.x, +gridDim.x, ... and prefetches the first chunk
 // of its next tile during the last chunk of the current one, so only the first tile pays the cold
@@ -92,26 +93,26 @@ __device__ __forceinline__ void apply_rule(int rule, float p0, float p1, float p
   }
 }
 
-__host__ __device__ constexpr int conv_kgs(int nhalo) {
-  // smallest value >= nhalo*16 that is == 32 (mod 128)
-  int b = nhalo * 16;
-  int r = ((32 - (b % 128)) + 128) % 128;
-  return b + r;
-}
-
 template <int P, int KC, int NW, int MW, int WAVES>
 struct ConvCfg {
   static constexpr int NT = WAVES * 64;
   static constexpr int TH = WAVES * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
   static constexpr int KG = KC / 8, BN = 32 * NW;
-  static constexpr int KGS = conv_kgs(NHALO);
-  static constexpr int HALO_BYTES = P * KG * KGS;
+  // Halo image in LDS = a sequence of 1 KiB pieces, each written by ONE LDS-DMA wave-instruction:
+  //   piece = PPP consecutive halo pixels x U units, laid out [unit][pixel][8 halves]
+  //   unit  = plane * KG + k-group (8 channels) -- U = P * KG of them, PPP = 64 / U pixels per piece
+  // so a fragment read (32 consecutive pixels of one unit) is made of contiguous runs of PPP * 16 bytes
+  // (a multiple of 256 B: conflict-free ds_read_b128, also where a run wraps into the next piece).
+  static constexpr int U = P * KG;
+  static constexpr int PPP = 64 / U;
+  static constexpr int HALO_PIECES = (NHALO + PPP - 1) / PPP;
+  static constexpr int HALO_BYTES = HALO_PIECES * 1024;
+  static constexpr int HALO_ITERS = (HALO_PIECES + WAVES - 1) / WAVES;   // DMA pieces per wave and chunk
   static constexpr int SLAB_BYTES = P * 9 * KC * BN * 2;
   static constexpr int BUF_BYTES = HALO_BYTES + SLAB_BYTES;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-  static constexpr int HALO_ITEMS = NHALO * P * KG;
-  static constexpr int HALO_ITERS = (HALO_ITEMS + NT - 1) / NT;
   static constexpr int SLAB_PIECES = SLAB_BYTES / 1024;   // one LDS-DMA wave-instruction = 1 KiB
+  static_assert(U == 2 || U == 4, "unit count per pixel");
   static_assert(SLAB_BYTES % 1024 == 0, "slab must be a whole number of 1 KiB DMA pieces");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -134,6 +135,17 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// The same for a buffer-addressed source: per-lane byte offset `voff` into the buffer `rsrc` plus the
+// wave-uniform `soff`; lanes whose offset lies outside the buffer write ZEROS to their 16 bytes of LDS
+// (checked on gfx950) -- which is how the convolution's zero padding gets into the halo image.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
                : "memory");
 }
 
@@ -187,7 +199,7 @@ template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false
 __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs a) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
-  constexpr int KG = C::KG, BN = C::BN, KGS = C::KGS;
+  constexpr int KG = C::KG, BN = C::BN, PPP = C::PPP;
   constexpr int ITERS = C::HALO_ITERS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -200,20 +212,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   const int nch0 = (a.C0 + KC - 1) / KC;
   const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
 
-  // ---- tile-invariant halo item geometry (per thread: ITERS items of 16 bytes)
-  int hyx[ITERS];      // (hy << 8) | hx of the halo pixel, -1 = unused item
-  int plkg[ITERS];     // (pl << 8) | kg*8
-  int ldsoff[ITERS];   // byte offset inside the halo image
+  // ---- tile-invariant halo geometry: wave w issues the DMA pieces w, w + WAVES, ...; in a piece, lane l
+  // fetches unit l / PPP of halo pixel piece * PPP + l % PPP
+  const int my_u = lane / PPP;
+  const int my_pl = my_u / KG, my_k8 = (my_u % KG) * 8;    // plane and first channel (within the chunk) of this lane's unit
+  int hyx[ITERS];      // (hy << 8) | hx of the halo pixel, -1 = no pixel (tail of the last piece)
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int i = tid + it * NT;
-    const int kg = i % KG;
-    const int pl = (i / KG) % P;
-    const int hp = i / (KG * P);
+    const int hp = (wave + it * WAVES) * PPP + lane % PPP;
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-    hyx[it] = (i < C::HALO_ITEMS) ? ((hy << 8) | hx) : -1;
-    plkg[it] = (pl << 8) | (kg * 8);
-    ldsoff[it] = (pl * KG + kg) * KGS + hp * 16;
+    hyx[it] = (hp < C::NHALO) ? ((hy << 8) | hx) : -1;
   }
 
   // ---- per-tile state: the tile being computed (cur_*) and the source state of the tile whose
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     for (int it = 0; it < ITERS; ++it) {
       const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      const int pl = plkg[it] >> 8, k8 = plkg[it] & 255;       // k8 = 8 * (k-group inside the chunk)
+      const int pl = my_pl, k8 = my_k8;                        // k8 = 8 * (k-group inside the chunk)
       const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
       const unsigned pix = (unsigned)((gy * W + gx) * P + pl);
       // k-groups 0,1 of a chunk sit in its first channel block, 2,3 (KC = 32) in the next one
@@ -256,16 +264,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     wsrc = (const char*)a.wpk + (size_t)ct * a.nchunks * C::SLAB_BYTES;
   };
 
-  u32x4 hv[ITERS];
-  auto halo_issue_one = [&](int c, int it) {     // `it` is a compile-time constant at every call site
+  // halo piece `it` of this wave for chunk c, straight into the halo image at LDS byte offset `halo_off`:
+  // no staging registers, no ds_write.  `it` is a compile-time constant at every call site.
+  auto halo_dma_one = [&](int c, int halo_off, int it) {
+    const int piece = wave + it * WAVES;
+    if (C::HALO_PIECES % WAVES != 0 && piece >= C::HALO_PIECES) return;
+    const unsigned dst = lds_base + halo_off + piece * 1024;
     // scalar offset = first channel block of the chunk
-    if (c < nch0) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc0, (int)voff0[it], c * (KC / 16) * (int)plane_bytes0, 0);
-    else hv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc1, (int)voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, 0);
-  };
-  auto halo_commit = [&](char* halo) {
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it)
-      if (hyx[it] >= 0) *(u32x4*)(halo + ldsoff[it]) = hv[it];
+    if (c < nch0) blds16(rsrc0, voff0[it], c * (KC / 16) * (int)plane_bytes0, dst);
+    else blds16(rsrc1, voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, dst);
   };
   constexpr int DMA_PER_WAVE = (C::SLAB_PIECES + WAVES - 1) / WAVES;
   auto slab_dma_one = [&](int c, int slab_off, int p) {
@@ -274,8 +281,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       glds16(wsrc + (size_t)c * C::SLAB_BYTES + piece * 1024, lane * 16, lds_base + slab_off + piece * 1024);
   };
 
-  // lane-constant LDS read offsets
-  const int a_lane_off = (lane >> 5) * KGS + ((wave * MW) * HALO_W + (lane & 31)) * 16;
+  // lane-constant LDS read offsets.  Pixel fragment of halo row r (0 .. MW+1 of this wave) shifted by dx:
+  // lane l reads unit (l >> 5) of pixel hp = (wave*MW + r) * HALO_W + (l & 31) + dx.
+  int a_off[MW + 2][3];
+#pragma unroll
+  for (int r = 0; r < MW + 2; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hp = (wave * MW + r) * HALO_W + (lane & 31) + dx;
+      a_off[r][dx] = (hp / PPP) * 1024 + ((lane >> 5) * PPP + hp % PPP) * 16;
+    }
   const int b_lane_off = ((lane >> 5) * BN + (lane & 31)) * 16;
 
   struct Frag { half8 ah[MW], al[MW], bh[NW], bl[NW]; };
@@ -284,9 +299,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
-      const int off = a_lane_off + (2 * s) * KGS + ((m + dy) * HALO_W + dx) * 16;
-      f.ah[m] = *(const half8*)(halo + off);
-      if (P == 2) f.al[m] = *(const half8*)(halo + off + KG * KGS);
+      const char* p = halo + a_off[m + dy][dx] + (2 * s) * PPP * 16;      // k-groups 2s, 2s+1
+      f.ah[m] = *(const half8*)p;
+      if (P == 2) f.al[m] = *(const half8*)(p + KG * PPP * 16);             // plane 1 = units KG ..
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -338,10 +353,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   decode(tile, cur_n, cur_y0, cur_x0, cur_ct);
   setup_sources(cur_n, cur_y0, cur_x0, cur_ct);
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) halo_issue_one(0, it);
+  for (int it = 0; it < ITERS; ++it) halo_dma_one(0, 0, it);
 #pragma unroll
   for (int p = 0; p < DMA_PER_WAVE; ++p) slab_dma_one(0, C::HALO_BYTES, p);
-  halo_commit(smem);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -358,8 +372,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     const bool have_next = next_tile < total_tiles;
     for (int c = 0; c < a.nchunks; ++c, ++g) {
       char* cur = smem + (g & 1) * C::BUF_BYTES;
-      char* nxt = smem + ((g & 1) ^ 1) * C::BUF_BYTES;
-      const int nxt_slab = ((g & 1) ^ 1) * C::BUF_BYTES + C::HALO_BYTES;
+      const int nxt_halo = ((g & 1) ^ 1) * C::BUF_BYTES;
+      const int nxt_slab = nxt_halo + C::HALO_BYTES;
       const bool last = c + 1 == a.nchunks;
       const bool more = !last || have_next;
       const int pc = last ? 0 : c + 1;          // chunk to prefetch (of this tile, or chunk 0 of the next)
@@ -395,11 +409,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
         if (more) {
 #pragma unroll
           for (int k = st * HPS; k < (st + 1) * HPS; ++k)
-            if (k < ITERS) halo_issue_one(pc, k);
+            if (k < ITERS) halo_dma_one(pc, nxt_halo, k);
 #pragma unroll
           for (int k = st * DPS; k < (st + 1) * DPS; ++k)
             if (k < DMA_PER_WAVE) slab_dma_one(pc, nxt_slab, k);
-          if (st == NSTEPS - 1) halo_commit(nxt);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep prefetch + load issue ahead of this step's MFMAs
         run_mfma(fc);
