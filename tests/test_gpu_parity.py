@@ -478,3 +478,28 @@ def test_determinism_side_stream_and_threads(torch_cuda, syn):
         t.join()
     for outs in results.values():
         assert len(outs) == 5 and all(torch.equal(o, a) for o in outs)
+
+
+def test_small_grid_tiles_are_bitwise_the_same(torch_cuda, syn):
+    """Small batches run the pool-free layers with 8-row tiles (twice the workgroups), large ones with 16-row
+    tiles; a frame's logits must not depend on which tile height computed it."""
+    torch = torch_cuda
+    B, H, W = 12, 256, 256
+    frames = syn.make_frames_u8(B, H, W, "smooth", 31)
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    for prec in ("exact", "fast"):
+        m, _ = make_model(3, True, 2, prec, syn, B, (H, W))
+        m(x[:1])                                   # creates the engine
+        m.profile(True)
+        one = m(x[:1])
+        torch.cuda.synchronize()
+        names_1 = [r[0] for r in m.profile_read()]
+        m.profile(True)
+        full = m(x)
+        torch.cuda.synchronize()
+        names_b = [r[0] for r in m.profile_read()]
+        m.profile(False)
+        pick = lambda names, layer: next(n for n in names if n.startswith(layer + "|"))
+        rows = lambda n: int(n.split("<")[1].split(",")[3])          # the MW template argument
+        assert rows(pick(names_1, "conv1_3.conv1")) == 1 and rows(pick(names_b, "conv1_3.conv1")) == 2
+        assert torch.equal(one, full[:1]), prec

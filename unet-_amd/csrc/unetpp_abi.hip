@@ -201,21 +201,39 @@ hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, bool head, hipStream_t 
   if constexpr (NW == 1) {
     if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(a, s);
   }
-  if (pool) return launch_conv_k<P, KC, NW, MW, WAVES, true, false>(a, s);
+  if constexpr (MW == 2) {     // the fused 2x2 pool needs both rows of a window in one wave
+    if (pool) return launch_conv_k<P, KC, NW, MW, WAVES, true, false>(a, s);
+  }
+  if (pool) return hipErrorInvalidValue;
   return launch_conv_k<P, KC, NW, MW, WAVES, false, false>(a, s);
 }
 
-hipError_t launch_conv(int P, const ConvLayer& L, const ConvArgs& a, bool head, hipStream_t s) {
-#define CASE(p, kc, nw, mw, wv) \
-  if (P == p && L.KC == kc && L.NW == nw && L.MW == mw && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw, wv>(a, L.do_pool, head, s);
+// `mw` = rows per wave: the layer's own (2: 16-row tiles) or 1 (8-row tiles, see small_grid_rows)
+hipError_t launch_conv(int P, const ConvLayer& L, int mw, const ConvArgs& a, bool head, hipStream_t s) {
+#define CASE(p, kc, nw, mw_, wv) \
+  if (P == p && L.KC == kc && L.NW == nw && mw == mw_ && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw_, wv>(a, L.do_pool, head, s);
   CASE(1, 16, 1, 2, 8)
   CASE(1, 32, 2, 2, 8)
   CASE(1, 16, 2, 2, 8)
   CASE(1, 16, 4, 2, 8)
   CASE(2, 16, 1, 2, 8)
   CASE(2, 16, 2, 2, 8)
+  CASE(1, 16, 2, 1, 8)
+  CASE(1, 32, 2, 1, 8)
+  CASE(1, 16, 4, 1, 8)
+  CASE(2, 16, 2, 1, 8)
 #undef CASE
   return hipErrorInvalidValue;
+}
+
+// Small batches leave the deep layers with fewer 16x32-pixel tiles than the chip has CUs (B=1: 16 tiles at 32x32).
+// Layers without a fused pool (its 2x2 window needs both rows in one wave) then run 8-row tiles: twice the
+// workgroups, each with half the matrix work per K-chunk.  Every output is still accumulated chunk by chunk, tap by
+// tap in the same order, so the result is bitwise the same whichever tile height ran (tested).
+int small_grid_rows(const ConvLayer& L, int nb, int H, int W, bool head) {
+  if (L.do_pool || head || L.NW == 1 || L.MW != 2) return L.MW;
+  const int tiles = nb * ((W + 31) / 32) * ((H + 15) / 16) * (L.cout / (32 * L.NW));
+  return tiles < g_num_cus ? 1 : L.MW;
 }
 
 void choose_cfg(int P, int cin_tensor, ConvLayer& L) {
@@ -642,7 +660,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = tp(L.out);
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
-        const int TH = L.WAVES * L.MW;
+        const int mw = small_grid_rows(L, nb, H, W, head);
+        const int TH = L.WAVES * mw;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
         a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
         double px = (double)nb * H * W;
@@ -658,8 +677,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           head_done = true;
         }
         char lbl[128];
-        snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, L.MW, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
-        Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, a, head, s); });
+        snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
+        Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, mw, a, head, s); });
       } else if (op.kind == OP_UP) {
         const Tensor& low = e->tensors[op.idx];
         const Tensor& dst = e->tensors[op.out];
