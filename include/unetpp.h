@@ -12,6 +12,7 @@
  * unetpp_forward() is asynchronous on `stream` and never synchronises.  One engine per device;
  * an engine is not thread-safe, independent engines are.  The caller owns all I/O buffers; the
  * library owns packed weights and the activation workspace and never keeps a caller pointer.
+ * Every call makes the engine's device the calling thread's current HIP device (hipSetDevice) and leaves it so.
  */
 #ifndef UNETPP_H
 #define UNETPP_H

@@ -92,6 +92,7 @@ struct unetpp_engine {
   unetpp_config cfg{};
   int P = 2;
   int mb = 1;
+  int num_cus = 256;
   std::string err;
   char* arena = nullptr;
   size_t arena_bytes = 0;
@@ -179,39 +180,40 @@ size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
 }
 
 // ---- conv dispatch ---------------------------------------------------------------------------
-int g_num_cus = 256;
+struct LaunchCtx { int device; int num_cus; };   // per engine: one process may drive engines on several devices
 
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
-hipError_t launch_conv_k(const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES>;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
-  dim3 grid((unsigned)std::min(total, g_num_cus * per_cu));
+  dim3 grid((unsigned)std::min(total, cx.num_cus * per_cu));
   auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD>;
-  static int attr_lds = 0;
-  if (attr_lds < lds) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
+  static int attr_lds[64] = {};       // the attribute is per device: remember what each one was given
+  int& have = attr_lds[cx.device & 63];
+  if (have < lds) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); have = lds; }
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
 }
 
 template <int P, int KC, int NW, int MW, int WAVES>
-hipError_t launch_conv_cfg(const ConvArgs& a, bool pool, bool head, hipStream_t s) {
+hipError_t launch_conv_cfg(const LaunchCtx& cx, const ConvArgs& a, bool pool, bool head, hipStream_t s) {
   if constexpr (NW == 1) {
-    if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(a, s);
+    if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(cx, a, s);
   }
   if constexpr (MW == 2) {     // the fused 2x2 pool needs both rows of a window in one wave
-    if (pool) return launch_conv_k<P, KC, NW, MW, WAVES, true, false>(a, s);
+    if (pool) return launch_conv_k<P, KC, NW, MW, WAVES, true, false>(cx, a, s);
   }
   if (pool) return hipErrorInvalidValue;
-  return launch_conv_k<P, KC, NW, MW, WAVES, false, false>(a, s);
+  return launch_conv_k<P, KC, NW, MW, WAVES, false, false>(cx, a, s);
 }
 
 // `mw` = rows per wave: the layer's own (2: 16-row tiles) or 1 (8-row tiles, see small_grid_rows)
-hipError_t launch_conv(int P, const ConvLayer& L, int mw, const ConvArgs& a, bool head, hipStream_t s) {
+hipError_t launch_conv(const LaunchCtx& cx, int P, const ConvLayer& L, int mw, const ConvArgs& a, bool head, hipStream_t s) {
 #define CASE(p, kc, nw, mw_, wv) \
-  if (P == p && L.KC == kc && L.NW == nw && mw == mw_ && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw_, wv>(a, L.do_pool, head, s);
+  if (P == p && L.KC == kc && L.NW == nw && mw == mw_ && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw_, wv>(cx, a, L.do_pool, head, s);
   CASE(1, 16, 1, 2, 8)
   CASE(1, 32, 2, 2, 8)
   CASE(1, 16, 2, 2, 8)
@@ -230,10 +232,10 @@ hipError_t launch_conv(int P, const ConvLayer& L, int mw, const ConvArgs& a, boo
 // Layers without a fused pool (its 2x2 window needs both rows in one wave) then run 8-row tiles: twice the
 // workgroups, each with half the matrix work per K-chunk.  Every output is still accumulated chunk by chunk, tap by
 // tap in the same order, so the result is bitwise the same whichever tile height ran (tested).
-int small_grid_rows(const ConvLayer& L, int nb, int H, int W, bool head) {
+int small_grid_rows(const ConvLayer& L, int num_cus, int nb, int H, int W, bool head) {
   if (L.do_pool || head || L.NW == 1 || L.MW != 2) return L.MW;
   const int tiles = nb * ((W + 31) / 32) * ((H + 15) / 16) * (L.cout / (32 * L.NW));
-  return tiles < g_num_cus ? 1 : L.MW;
+  return tiles < num_cus ? 1 : L.MW;
 }
 
 void choose_cfg(int P, int cin_tensor, ConvLayer& L) {
@@ -442,12 +444,12 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     return fail(nullptr, UNETPP_E_HIP, "no HIP device available: this engine has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, UNETPP_E_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
   HIP_TRY(nullptr, hipSetDevice(cfg->device));
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
-  }
 
   unetpp_engine* e = new unetpp_engine();
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+  }
   e->cfg = *cfg;
   e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
@@ -501,11 +503,17 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     e->convts[i].mult = (float*)(e->arena + tmu[i]);
   }
   if (e->nstreams > 1) {
-    for (int i = 0; i < e->nstreams; ++i) {
-      HIP_TRY(nullptr, hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking));
-      HIP_TRY(nullptr, hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming));
+    hipError_t se = hipSuccess;
+    for (int i = 0; i < e->nstreams && se == hipSuccess; ++i) {
+      se = hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking);
+      if (se == hipSuccess) se = hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming);
     }
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
+    if (se == hipSuccess) se = hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming);
+    if (se != hipSuccess) {
+      std::string m = hipGetErrorString(se);
+      unetpp_destroy(e);                       // frees the arena and whatever streams/events exist
+      return fail(nullptr, UNETPP_E_HIP, "stream/event creation: %s", m.c_str());
+    }
   }
   *out = e;
   return UNETPP_OK;
@@ -660,7 +668,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = tp(L.out);
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
-        const int mw = small_grid_rows(L, nb, H, W, head);
+        const int mw = small_grid_rows(L, e->num_cus, nb, H, W, head);
         const int TH = L.WAVES * mw;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
         a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
@@ -678,7 +686,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         }
         char lbl[128];
         snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
-        Lx.run(lbl, flops, bytes, [&] { return launch_conv(P, L, mw, a, head, s); });
+        Lx.run(lbl, flops, bytes, [&] { return launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s); });
       } else if (op.kind == OP_UP) {
         const Tensor& low = e->tensors[op.idx];
         const Tensor& dst = e->tensors[op.out];
