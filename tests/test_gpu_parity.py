@@ -162,7 +162,9 @@ def test_errors(torch_cuda, syn):
 
 @pytest.mark.parametrize("C,B,H,W", [(3, 1, 16, 16), (3, 3, 16, 80), (7, 2, 80, 16), (3, 2, 112, 144), (7, 1, 32, 224),
                                      # every class count the reference's callers construct (2, 3, 4, 6, 7) and the limits 1, 8
-                                     (1, 1, 16, 32), (2, 1, 32, 48), (4, 2, 48, 32), (6, 1, 32, 64), (8, 1, 16, 48)])
+                                     (1, 1, 16, 32), (2, 1, 32, 48), (4, 2, 48, 32), (6, 1, 32, 64), (8, 1, 16, 48),
+                                     # one tile row / one tile column of maximal length
+                                     (3, 1, 16, 4096), (3, 1, 4096, 16)])
 def test_ragged_shapes_against_oracle(C, B, H, W, torch_cuda, syn, oracle):
     """Minimum size, single row/column of tiles, widths that are not multiples of the 32-pixel tile
     (80 = 2.5 tiles, 144 = 4.5), heights that are not multiples of the 16-row tile: oracle on the host."""
