@@ -93,7 +93,7 @@ __device__ __forceinline__ void apply_rule(int rule, float p0, float p1, float p
   }
 }
 
-template <int P, int KC, int NW, int MW, int WAVES>
+template <int P, int KC, int NW, int MW, int WAVES, bool SINGLE = false>
 struct ConvCfg {
   static constexpr int NT = WAVES * 64;
   static constexpr int TH = WAVES * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
@@ -110,7 +110,13 @@ struct ConvCfg {
   static constexpr int HALO_ITERS = (HALO_PIECES + WAVES - 1) / WAVES;   // DMA pieces per wave and chunk
   static constexpr int SLAB_BYTES = P * 9 * KC * BN * 2;
   static constexpr int BUF_BYTES = HALO_BYTES + SLAB_BYTES;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  // Stage buffers per workgroup: two (the next chunk loads under this chunk's MFMAs; one workgroup per CU in exact
+  // mode), or with SINGLE one, so that two workgroups fit a CU.  The load, matrix and epilogue phases of a single
+  // workgroup's lock-stepped waves do not overlap each other (measured: they add up); those of two workgroups do.
+  // It pays where HBM is not the limit anyway: the fused-head conv, which reads x0_4a and writes one byte per pixel
+  // (265 -> 221 us); the other full-resolution convs already run at the HBM rate and stay double-buffered.
+  static constexpr int STAGES = SINGLE ? 1 : 2;
+  static constexpr int LDS_BYTES = STAGES * BUF_BYTES;
   static constexpr int SLAB_PIECES = SLAB_BYTES / 1024;   // one LDS-DMA wave-instruction = 1 KiB
   static_assert(U == 2 || U == 4, "unit count per pixel");
   static_assert(SLAB_BYTES % 1024 == 0, "slab must be a whole number of 1 KiB DMA pieces");
@@ -195,9 +201,13 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
 constexpr int HEAD_MAX_CLASSES = 16;
 constexpr int HEAD_FUSED_MAX_CLASSES = 8;   // the fused head keeps all logits in registers
 
+// the exact-mode fused-head kernel runs single-staged, two workgroups per CU (see ConvCfg::STAGES)
+template <int P, bool HEAD> constexpr bool conv_single_stage() { return HEAD && P == 2; }
+
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false>
-__global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs a) {
-  using C = ConvCfg<P, KC, NW, MW, WAVES>;
+__global__ __launch_bounds__(WAVES * 64, (conv_single_stage<P, HEAD>() ? 2 : 1))
+void conv3x3_bias_relu_kernel(ConvArgs a) {
+  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>()>;
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
   constexpr int KG = C::KG, BN = C::BN, PPP = C::PPP;
   constexpr int ITERS = C::HALO_ITERS;
@@ -356,10 +366,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
   for (int it = 0; it < ITERS; ++it) halo_dma_one(0, 0, it);
 #pragma unroll
   for (int p = 0; p < DMA_PER_WAVE; ++p) slab_dma_one(0, C::HALO_BYTES, p);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  constexpr int STAGES = C::STAGES;
+  if (STAGES == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
-  int g = 0;   // global chunk counter: chunk g lives in stage buffer g & 1
+  int g = 0;   // global chunk counter: chunk g lives in stage buffer g & 1 (two stages) or 0 (one)
   for (;;) {
 #pragma unroll
     for (int m = 0; m < MW; ++m)
@@ -371,8 +384,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
     const int next_tile = tile + (int)gridDim.x;
     const bool have_next = next_tile < total_tiles;
     for (int c = 0; c < a.nchunks; ++c, ++g) {
-      char* cur = smem + (g & 1) * C::BUF_BYTES;
-      const int nxt_halo = ((g & 1) ^ 1) * C::BUF_BYTES;
+      char* cur = smem + (STAGES == 2 ? (g & 1) : 0) * C::BUF_BYTES;
+      const int nxt_halo = (STAGES == 2 ? ((g & 1) ^ 1) : 0) * C::BUF_BYTES;
       const int nxt_slab = nxt_halo + C::HALO_BYTES;
       const bool last = c + 1 == a.nchunks;
       const bool more = !last || have_next;
@@ -399,6 +412,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
       constexpr int SPREAD = (NW == 1) ? UNETPP_SPREAD_NW1 : NSTEPS - 1;
       constexpr int HPS = (ITERS + SPREAD - 1) / SPREAD;          // halo items issued per step
       constexpr int DPS = (DMA_PER_WAVE + SPREAD - 1) / SPREAD;   // DMA pieces issued per step
+      if (STAGES == 1) {      // the chunk's requests went out after the previous chunk's MFMAs (or in the prologue)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       Frag f0, f1;
       load_frags(f0, halo, slab, 0);
 #pragma unroll
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
         Frag& fc = (st & 1) ? f1 : f0;
         Frag& fn = (st & 1) ? f0 : f1;
         if (st + 1 < NSTEPS) load_frags(fn, halo, slab, st + 1);
-        if (more) {
+        if (STAGES == 2 && more) {
 #pragma unroll
           for (int k = st * HPS; k < (st + 1) * HPS; ++k)
             if (k < ITERS) halo_dma_one(pc, nxt_halo, k);
@@ -418,8 +435,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_bias_relu_kernel(ConvArgs 
         run_mfma(fc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-      __syncthreads();
+      if (STAGES == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+        __syncthreads();
+      } else {
+        __syncthreads();                                    // every wave has read its last fragments: the stage is free
+        if (more) {
+#pragma unroll
+          for (int k = 0; k < ITERS; ++k) halo_dma_one(pc, 0, k);
+#pragma unroll
+          for (int k = 0; k < DMA_PER_WAVE; ++k) slab_dma_one(pc, C::HALO_BYTES, k);
+        }
+      }
     }
 
     // ---- epilogue straight from registers: scale, bias, ReLU, fp16 (hi/lo) packing, one

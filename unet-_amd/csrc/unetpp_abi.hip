@@ -184,7 +184,7 @@ struct LaunchCtx { int device; int num_cus; };   // per engine: one process may 
 
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
 hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) {
-  using C = ConvCfg<P, KC, NW, MW, WAVES>;
+  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>()>;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
