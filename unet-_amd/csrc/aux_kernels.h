@@ -115,9 +115,9 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
   // most three) low-res rows they interpolate are staged ONCE in LDS with full-line loads, so the four
   // corner reads per output are LDS reads: the vector-memory pipe only sees ~1.75 instructions per output
   // KiB instead of 10 (the register version was bound by the address coalescer, not by HBM).
-  // One thread stores ONE 16-byte piece, so a wave's store is 1 KiB of consecutive bytes; in EXACT mode the
-  // two threads that share a channel octet (lane ^ 2) each interpolate four of its eight channels (hi+lo
-  // in fp32) and swap halves with one DPP exchange.
+  // One thread stores one 16-byte piece of each of the two rows, so a wave's store is 1 KiB of consecutive bytes; in
+  // EXACT mode the two threads that share a channel octet (lane ^ 2) each interpolate four of its eight channels
+  // (hi+lo in fp32) and swap halves with one DPP exchange.
   // Workgroups r, r+8, ... share an XCD (round-robin dispatch): the row-pair index is permuted so that each
   // XCD owns a contiguous band of rows and neighbouring row pairs find their shared low-res row in its L2.
   constexpr int PIECES = 2 * P;
@@ -148,63 +148,83 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
     }
   }
   __syncthreads();
-  const int row_items = (xo1 - xo0) * PIECES;  // multiple of 64: every wave is full (DPP exchange below)
-  for (int idx = threadIdx.x; idx < 2 * row_items; idx += blockDim.x) {
-    const int yo = idx >= row_items;           // which of the two output rows (uniform per wave: 64 | row_items)
-    const int id2 = idx - yo * row_items;
-    const int y = 2 * r + yo;
+  // ---- one thread = one 16-byte piece of one output column, for BOTH output rows: the x-interpolation of the staged
+  // low-res rows (the expensive part: fp16 hi+lo -> fp32) is done once and shared; the rows differ only in their
+  // y-weights, folded into one weight per staged row (zero for a row that output row does not touch).
+  float wy[2][3];
+#pragma unroll
+  for (int ro = 0; ro < 2; ++ro) {
+    const int y = 2 * r + ro;
     const float fy = sh * (float)y;
     const int y0 = (int)fy;
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const float ly1 = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), ly0 = 1.f - ly1;
-    const int piece = id2 & (PIECES - 1);
-    const int x = xo0 + id2 / PIECES;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wy[ro][k] = (k == y0 - ybase ? ly0 : 0.f) + (k == y1 - ybase ? ly1 : 0.f);
+  }
+  const int row_items = (xo1 - xo0) * PIECES;  // multiple of 64: every wave is full (DPP exchange below)
+  for (int idx = threadIdx.x; idx < row_items; idx += blockDim.x) {
+    const int piece = idx & (PIECES - 1);
+    const int x = xo0 + idx / PIECES;
     const float fx = sw * (float)x;
     const int xg = (int)fx;                     // global low-res column
     const int x0 = xg - xbase;                  // column inside the staged segment
     const int x1 = x0 + (xg < w - 1 ? 1 : 0);
     const float lx1 = fminf(fmaxf(fx - (float)xg, 0.f), 1.f), lx0 = 1.f - lx1;
-    const half_t* r0 = rows + (size_t)(y0 - ybase) * wseg * REC;
-    const half_t* r1 = rows + (size_t)(y1 - ybase) * wseg * REC;
-    half_t* dst = out + ((nb * H + y) * W + x) * (size_t)REC + piece * 8;
+    half_t* dst = out + ((nb * H + 2 * r) * W + x) * (size_t)REC + piece * 8;      // output row 2r; row 2r+1 is W*REC further
     if (P == 2) {
       const int oct = piece & 1, role = piece >> 1;       // role 0 stores hi and computes channels 0-3 of the octet
       const int e0 = oct * 8 + role * 4;
-      half4v a00 = *(const half4v*)(r0 + x0 * REC + e0), a01 = *(const half4v*)(r0 + x1 * REC + e0);
-      half4v a10 = *(const half4v*)(r1 + x0 * REC + e0), a11 = *(const half4v*)(r1 + x1 * REC + e0);
-      half4v b00 = *(const half4v*)(r0 + x0 * REC + 16 + e0), b01 = *(const half4v*)(r0 + x1 * REC + 16 + e0);
-      half4v b10 = *(const half4v*)(r1 + x0 * REC + 16 + e0), b11 = *(const half4v*)(r1 + x1 * REC + 16 + e0);
-      half4v rh, rl;
+      float t[3][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v00 = (float)a00[e] + (float)b00[e], v01 = (float)a01[e] + (float)b01[e];
-        float v10 = (float)a10[e] + (float)b10[e], v11 = (float)a11[e] + (float)b11[e];
-        float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-        half_t hi, lo;
-        split_f16(v, hi, lo);
-        rh[e] = hi; rl[e] = lo;
+      for (int k = 0; k < 3; ++k) {
+        const half_t* rk = rows + (size_t)k * wseg * REC + e0;
+        const half4v a0 = *(const half4v*)(rk + x0 * REC), a1 = *(const half4v*)(rk + x1 * REC);
+        const half4v b0 = *(const half4v*)(rk + x0 * REC + 16), b1 = *(const half4v*)(rk + x1 * REC + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)       // lx0 * (hi + lo) + lx1 * (hi + lo) as four mixed-precision FMAs
+          t[k][e] = fmaf(lx1, (float)b1[e], fmaf(lx1, (float)a1[e], fmaf(lx0, (float)b0[e], lx0 * (float)a0[e])));
       }
-      typedef __attribute__((ext_vector_type(2))) int int2v;
-      const int2v keep = __builtin_bit_cast(int2v, role ? rl : rh);
-      const int2v send = __builtin_bit_cast(int2v, role ? rh : rl);
-      int2v recv;
-      recv[0] = __builtin_amdgcn_mov_dpp(send[0], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]: lane ^ 2
-      recv[1] = __builtin_amdgcn_mov_dpp(send[1], 0x4E, 0xF, 0xF, true);
-      // hi lane: [own channels 0-3 | partner's 4-7]; lo lane: [partner's 0-3 | own 4-7]
-      u32x4 o = role ? u32x4{(unsigned)recv[0], (unsigned)recv[1], (unsigned)keep[0], (unsigned)keep[1]}
-                     : u32x4{(unsigned)keep[0], (unsigned)keep[1], (unsigned)recv[0], (unsigned)recv[1]};
-      __builtin_nontemporal_store(o, (u32x4*)dst);     // written once, next read after >1 GB of other traffic
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro) {
+        half4v rh, rl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(wy[ro][2], t[2][e], fmaf(wy[ro][1], t[1][e], wy[ro][0] * t[0][e]));
+          half_t hi, lo;
+          split_f16(v, hi, lo);
+          rh[e] = hi; rl[e] = lo;
+        }
+        typedef __attribute__((ext_vector_type(2))) int int2v;
+        const int2v keep = __builtin_bit_cast(int2v, role ? rl : rh);
+        const int2v send = __builtin_bit_cast(int2v, role ? rh : rl);
+        int2v recv;
+        recv[0] = __builtin_amdgcn_mov_dpp(send[0], 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]: lane ^ 2
+        recv[1] = __builtin_amdgcn_mov_dpp(send[1], 0x4E, 0xF, 0xF, true);
+        // hi lane: [own channels 0-3 | partner's 4-7]; lo lane: [partner's 0-3 | own 4-7]
+        u32x4 o = role ? u32x4{(unsigned)recv[0], (unsigned)recv[1], (unsigned)keep[0], (unsigned)keep[1]}
+                       : u32x4{(unsigned)keep[0], (unsigned)keep[1], (unsigned)recv[0], (unsigned)recv[1]};
+        // written once, next read after >1 GB of other traffic
+        __builtin_nontemporal_store(o, (u32x4*)(dst + (size_t)ro * W * REC));
+      }
     } else {
       const int e0 = piece * 8;
-      half8 a00 = *(const half8*)(r0 + x0 * REC + e0), a01 = *(const half8*)(r0 + x1 * REC + e0);
-      half8 a10 = *(const half8*)(r1 + x0 * REC + e0), a11 = *(const half8*)(r1 + x1 * REC + e0);
-      half8 rr;
+      float t[3][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = ly0 * (lx0 * (float)a00[e] + lx1 * (float)a01[e]) + ly1 * (lx0 * (float)a10[e] + lx1 * (float)a11[e]);
-        rr[e] = (half_t)v;
+      for (int k = 0; k < 3; ++k) {
+        const half_t* rk = rows + (size_t)k * wseg * REC + e0;
+        const half8 a0 = *(const half8*)(rk + x0 * REC), a1 = *(const half8*)(rk + x1 * REC);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[k][e] = fmaf(lx1, (float)a1[e], lx0 * (float)a0[e]);
       }
-      __builtin_nontemporal_store(rr, (half8*)dst);
+#pragma unroll
+      for (int ro = 0; ro < 2; ++ro) {
+        half8 rr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          rr[e] = (half_t)fmaf(wy[ro][2], t[2][e], fmaf(wy[ro][1], t[1][e], wy[ro][0] * t[0][e]));
+        __builtin_nontemporal_store(rr, (half8*)(dst + (size_t)ro * W * REC));
+      }
     }
   }
 }

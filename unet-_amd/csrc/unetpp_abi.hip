@@ -696,7 +696,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         const int nseg = (W + UP_SEG - 1) / UP_SEG;
         const int seg_w = std::min(W, UP_SEG);
         const size_t up_lds = (size_t)3 * (seg_w / 2 + 2) * P * 32;      // staged low-res rows of one segment
-        const int up_threads = seg_w * 2 * P >= 1024 ? 512 : 256;
+        const int up_threads = seg_w * 2 * P >= 1024 ? 512 : (seg_w * 2 * P >= 256 ? 256 : 128);   // one item = both rows of a piece
         char nm[64];
         snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", dst.lvl, P);
         Lx.run(nm, px * low.C * 8, bytes, [&] {
