@@ -1,6 +1,8 @@
 // Dev tool (not part of the product): times one conv3x3 configuration on random data.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DUNETPP_ABLATE_MFMA|-DUNETPP_ABLATE_GLOBAL] -o conv_bench scripts/conv_bench.hip
-// usage: conv_bench P KC NW N H W C0 C1 Cout [reps]
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/conv_bench scripts/conv_bench.hip
+// usage: [CB_DATA=0|1|2] conv_bench P KC NW N H W C0 C1 Cout [reps [MW [WAVES]]]
+//   CB_DATA: operand values 0 = zeros, 1 = uniform [-1,1] (default), 2 = ReLU-like (half zeros, half [0,1]) - the rate the
+//   chip sustains depends on them
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +50,9 @@ int main(int argc, char** argv) {
   size_t nw = (size_t)(a.C0 + a.C1 + 32) * 9 * a.Cout * P + 65536;
   std::vector<half_t> h(std::max(std::max(n0, n1), nw));
   srand(1);
-  for (auto& v : h) v = (half_t)((rand() % 2001 - 1000) / 1000.0f);
+  { const char* z = getenv("CB_DATA"); const int mode = z ? atoi(z) : 1;
+    for (auto& v : h) v = mode == 0 ? (half_t)0.f : mode == 1 ? (half_t)((rand() % 2001 - 1000) / 1000.0f)
+                                   : (rand() % 2 ? (half_t)((rand() % 1001) / 1000.0f) : (half_t)0.f); }
   half_t *d0, *d1, *dw, *dout; float *sc, *bi;
   CK(hipMalloc(&d0, n0 * 2)); CK(hipMalloc(&d1, n1 * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dout, no * 2));
   CK(hipMalloc(&sc, a.Cout * 4)); CK(hipMalloc(&bi, a.Cout * 4));
