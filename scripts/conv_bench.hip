@@ -30,11 +30,6 @@ float run(ConvArgs a, int reps) {
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("grid %u LDS %d\n", grid.x, C::LDS_BYTES);
-#ifdef UNETPP_STAMP
-  unsigned long long hs[32];
-  CK(hipMemcpy(hs, a.pool_out, sizeof hs, hipMemcpyDeviceToHost));
-  for (int w = 0; w < 8; ++w) printf("wave %d cycles: prologue %llu | per-chunk mfma %llu barrier %llu (x%d chunks) | epilogue %llu\n", w, hs[w*4], hs[w*4+1]/a.nchunks, hs[w*4+2]/a.nchunks, a.nchunks, hs[w*4+3]);
-#endif
   return ms / reps;
 }
 
@@ -60,9 +55,6 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dw, h.data(), nw * 2, hipMemcpyHostToDevice));
   std::vector<float> ones(a.Cout, 1e-3f); CK(hipMemcpy(sc, ones.data(), a.Cout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, ones.data(), a.Cout * 4, hipMemcpyHostToDevice));
   a.in0 = d0; a.in1 = a.C1 ? d1 : nullptr; a.wpk = dw; a.scale = sc; a.bias = bi; a.out = dout; a.pool_out = nullptr;
-#ifdef UNETPP_STAMP
-  { half_t* dbg; CK(hipMalloc(&dbg, 4096)); a.pool_out = dbg; }
-#endif
   float ms = -1;
 #define CASE(p, kc, nw_, mw, wv) if (P == p && KC == kc && NW == nw_ && MW == mw && WV == wv) ms = run<p, kc, nw_, mw, wv>(a, reps);
   CASE(2, 16, 2, 2, 8) CASE(2, 16, 1, 2, 8) CASE(1, 16, 4, 2, 8) CASE(1, 32, 2, 2, 8) CASE(1, 32, 1, 2, 8)
