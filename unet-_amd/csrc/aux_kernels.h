@@ -106,7 +106,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 half4v;
 constexpr int UP_SEG = 256;                 // output columns per upsample workgroup
 
 template <int P>
-__global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restrict__ low, int Cu, int N, int H, int W,
+__global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restrict__ low, int H, int W,
                                                          half_t* __restrict__ out) {
   // Tensors are channel-blocked: [N][Cu/16][h][w][P][16]; a pixel record is 2*P pieces of 16 bytes
   // ([hi 0-7][hi 8-15][lo 0-7][lo 8-15] in EXACT mode).
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(1024) void upsample2x_kernel(const half_t* __restri
 // (apply_rule, conv3x3_mfma.h).  x is channel-blocked [N][Cx/16][H][W][P][16]; C <= HEAD_FUSED_MAX_CLASSES.
 template <int P>
 __global__ void head_generic_kernel(const half_t* __restrict__ x, int Cx, const float* __restrict__ w /*[C][Cx]*/,
-                                    const float* __restrict__ b, int C, int N, int H, int W,
+                                    const float* __restrict__ b, int C, int H, int W,
                                     float* __restrict__ logits, float* __restrict__ probs, uint8_t* __restrict__ mask,
                                     uint8_t* __restrict__ cable, uint8_t* __restrict__ tape, int rule, float t_cable,
                                     float t_tape, float bg_margin, float ct_margin) {

@@ -700,8 +700,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         char nm[64];
         snprintf(nm, sizeof nm, "up%d|upsample2x_kernel<%d>", dst.lvl, P);
         Lx.run(nm, px * low.C * 8, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
-          else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), low.C, nb, H, W, tp(op.out));
+          if (P == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), H, W, tp(op.out));
+          else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3((unsigned)((H / 2) * nseg), (unsigned)(nb * (low.C / 16))), dim3(up_threads), up_lds, s, tp(op.idx), H, W, tp(op.out));
           return hipSuccess;
         });
       } else if (op.kind == OP_CONVT) {
@@ -729,8 +729,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         dim3 grid((unsigned)((hw + 255) / 256), (unsigned)nb);
         const size_t lds = (size_t)(C * cx + C) * sizeof(float);
         Lx.run(P == 2 ? "final+argmax|head_generic_kernel<2>" : "final+argmax|head_generic_kernel<1>", 2.0 * total * cx * C, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(head_generic_kernel<2>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
-          else hipLaunchKernelGGL(head_generic_kernel<1>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, nb, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+          if (P == 2) hipLaunchKernelGGL(head_generic_kernel<2>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+          else hipLaunchKernelGGL(head_generic_kernel<1>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
           return hipSuccess;
         });
       }
