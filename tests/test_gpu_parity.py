@@ -506,3 +506,22 @@ def test_small_grid_tiles_are_bitwise_the_same(torch_cuda, syn):
         rows = lambda n: int(n.split("<")[1].split(",")[3])          # the MW template argument
         assert rows(pick(names_1, "conv1_3.conv1")) == 1 and rows(pick(names_b, "conv1_3.conv1")) == 2
         assert torch.equal(one, full[:1]), prec
+
+
+def test_random_shapes_against_oracle(torch_cuda, syn, oracle):
+    """Seeded sweep over (classes, batch, H, W, weight seed): every case against the CPU oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(20261004)
+    for _ in range(12):
+        C = int(rng.integers(1, 9)); B = int(rng.integers(1, 4))
+        H = 16 * int(rng.integers(1, 11)); W = 16 * int(rng.integers(1, 11))
+        wseed = int(rng.integers(0, 50))
+        frames = syn.make_frames_u8(B, H, W, "smooth" if rng.integers(0, 2) else "uniform", int(rng.integers(0, 1000)))
+        x = syn.frames_to_chw_f32(frames)
+        model, sd = make_model(C, C == 3, wseed, "exact", syn, B, (H, W))
+        ref = oracle.torch_forward(sd, x)
+        mask, logits = model.segment(torch.from_numpy(x).cuda(), return_logits=True)
+        torch.cuda.synchronize()
+        err, flips, unexplained = report(logits.cpu().numpy(), mask.cpu().numpy(), ref, oracle.masks_from_logits(ref)[0], oracle)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert err < 2e-5 * scale and unexplained == 0, (C, B, H, W, wseed, err, flips)
