@@ -525,3 +525,22 @@ def test_random_shapes_against_oracle(torch_cuda, syn, oracle):
         err, flips, unexplained = report(logits.cpu().numpy(), mask.cpu().numpy(), ref, oracle.masks_from_logits(ref)[0], oracle)
         scale = max(1.0, float(np.abs(ref).max()))
         assert err < 2e-5 * scale and unexplained == 0, (C, B, H, W, wseed, err, flips)
+
+
+def test_simple_unet_random_shapes_against_oracle(torch_cuda, syn, oracle):
+    """The same sweep for SimpleUNet (H, W multiples of 8; transposed-conv upsampling)."""
+    torch = torch_cuda
+    from unet_amd.nested_unet import SimpleUNet
+    rng = np.random.default_rng(41001)
+    for _ in range(8):
+        C = int(rng.integers(1, 9)); B = int(rng.integers(1, 4))
+        H = 8 * int(rng.integers(1, 17)); W = 8 * int(rng.integers(1, 17))
+        sd = syn.make_simple_state_dict(C, 3, int(rng.integers(0, 50)))
+        x = syn.frames_to_chw_f32(syn.make_frames_u8(B, H, W, "smooth", int(rng.integers(0, 1000))))
+        m = SimpleUNet(num_classes=C, num_channels=3, max_batch=B, max_hw=(H, W)).to("cuda:0")
+        m.load_state_dict(sd, strict=True)
+        ref = oracle.simple_unet_torch_forward(sd, x)
+        mask, logits = m.segment(torch.from_numpy(x).cuda(), return_logits=True)
+        torch.cuda.synchronize()
+        err, flips, unexplained = report(logits.cpu().numpy(), mask.cpu().numpy(), ref, oracle.masks_from_logits(ref)[0], oracle)
+        assert err < 5e-5 * max(1.0, float(np.abs(ref).max())) and unexplained == 0, (C, B, H, W, err, flips)
