@@ -8,14 +8,21 @@ runs its own 16-frame shard (weak scaling, config 3 = 8 x 16) with weights broad
 RCCL and no steady-state collective.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8                      # starts its own 8 ranks (one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W    # or under an external launcher (RANK/WORLD_SIZE in the env)
+
+Other workloads of SURVEY §8(d) come from the same script: `--classes 7 --height 448 --width 800 --batch 32`
+(config 4), `--height 1024 --width 1024 --batch 8` (config 5), `--arch simple --classes 7 --height 256 --width 256`
+(SimpleUNet, §8(f) row 3).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,34 +30,118 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GFLOP_PER_FRAME = {(3, 512, 512): 111.636}
 MFMA_F16_PEAK_TFLOPS = 2500.0                       # dense fp16 MFMA, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 
 
-def algorithmic_gflop(C, H, W):
-    nb = (32, 64, 128, 256, 512)
+def algorithmic_gflop(arch, C, H, W):
+    """2 x MACs of one frame (111.636 for the 3-class 512x512 NestedUNet)."""
     macs = 0
-    for l in range(5):
-        px = (H >> l) * (W >> l)
-        cin = 3 if l == 0 else nb[l - 1]
-        macs += px * 9 * (cin * nb[l] + nb[l] * nb[l])
-    for l in range(4):
-        px = (H >> l) * (W >> l)
-        macs += px * 9 * ((nb[l] + nb[l + 1]) * nb[l] + nb[l] * nb[l])
-    macs += H * W * 32 * C
+    if arch == "nested":
+        nb = (32, 64, 128, 256, 512)
+        for l in range(5):
+            px = (H >> l) * (W >> l)
+            cin = 3 if l == 0 else nb[l - 1]
+            macs += px * 9 * (cin * nb[l] + nb[l] * nb[l])
+        for l in range(4):
+            px = (H >> l) * (W >> l)
+            macs += px * 9 * ((nb[l] + nb[l + 1]) * nb[l] + nb[l] * nb[l])
+        macs += H * W * 32 * C
+    else:                                            # SimpleUNet, src/models/simple_unet.py:30-92
+        sb = (64, 128, 256, 512)
+        for l in range(4):
+            px = (H >> l) * (W >> l)
+            cin = 3 if l == 0 else sb[l - 1]
+            macs += px * 9 * (cin * sb[l] + sb[l] * sb[l])
+        for l in range(3):
+            px = (H >> l) * (W >> l)
+            macs += (px // 4) * 4 * sb[l + 1] * sb[l]                      # ConvTranspose2d k2 s2
+            macs += px * 9 * (2 * sb[l] * sb[l] + sb[l] * sb[l])
+        macs += H * W * 64 * C
     return 2.0 * macs / 1e9
 
 
-def cpu_baseline(sd, syn, C, H, W, n_frames, gpu_model, torch):
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` from a plain shell: start N fresh processes (one per GPU) and relay rank 0's JSON
+    line.  The parent never touches the GPU (no HIP call, nothing re-exec'ed), so every rank initialises its own
+    device from scratch; children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under torch.distributed.run."""
+    n = args.gpus
+    share = bool(os.environ.get("UNETPP_BENCH_SHARE_GPU")) or args.no_engine
+    if not share:
+        # device_count() does not initialise HIP; asked in a child anyway so that this process stays GPU-free
+        try:
+            q = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                               capture_output=True, text=True, timeout=600)
+            ndev = int(q.stdout.strip().splitlines()[-1]) if q.returncode == 0 and q.stdout.strip() else 0
+        except (subprocess.SubprocessError, ValueError):
+            ndev = 0
+        if ndev < n:
+            print(f"bench.py: --gpus {n} needs {n} HIP devices, this machine shows {ndev} "
+                  f"(one process per GPU; set UNETPP_BENCH_SHARE_GPU=1 only to rehearse the control flow)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UNETPP_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout carries the JSON line; the other ranks' stdout joins stderr so the parent prints one line
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    deadline = time.time() + float(os.environ.get("UNETPP_BENCH_TIMEOUT", "1500"))
+    first_fail = None
+    out0 = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if out0 is None and codes[0] is not None:
+            out0 = procs[0].stdout.read()
+        if all(c is not None for c in codes):
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and first_fail is None:
+            first_fail = time.time()
+        if (first_fail is not None and time.time() - first_fail > 15) or time.time() > deadline:
+            for p in procs:                      # a rank died (or the job hangs): stop exactly the ranks we started
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    if out0 is None:
+        out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = [p.poll() if p.poll() is not None else -9 for p in procs]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return worst if worst < 256 else 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(sd, syn, arch, C, H, W, n_frames, gpu_model, torch):
     """The oracle's torch-CPU restatement (what the reference's --device cpu path executes), batch 1
     per call like the reference frame loop, timed on this host's cores; the same frames go through
     the GPU engine and the two masks are compared."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unetpp_oracle as oracle
+    fwd = oracle.torch_forward if arch == "nested" else oracle.simple_unet_torch_forward
     frames = syn.make_frames_u8(n_frames, H, W, "smooth", 4321)
     x = syn.frames_to_chw_f32(frames)
+
+    def segment(xi):
+        lg = fwd(sd, xi)
+        return lg, oracle.masks_from_logits(lg)[0]
     # pick the thread count that serves this host best (the default of one thread per logical CPU
     # oversubscribes a 256-CPU box on a batch-1 conv net): 2 frames per candidate, then the timed sample
     default_threads = torch.get_num_threads()
@@ -59,20 +150,19 @@ def cpu_baseline(sd, syn, C, H, W, n_frames, gpu_model, torch):
         if nt > default_threads:
             continue
         torch.set_num_threads(nt)
-        oracle.torch_segment(sd, x[:1])                                 # warm
+        segment(x[:1])                                                   # warm
         t0 = time.perf_counter()
         for i in range(2):
-            oracle.torch_segment(sd, x[i:i + 1])
+            segment(x[i % n_frames:i % n_frames + 1])
         trials[nt] = 2 / (time.perf_counter() - t0)
     best_nt = max(trials, key=trials.get)
     torch.set_num_threads(best_nt)
-    oracle.torch_segment(sd, x[:1])
+    segment(x[:1])
     t0 = time.perf_counter()
-    ref_logits = [oracle.torch_forward(sd, x[i:i + 1]) for i in range(n_frames)]
-    ref_masks = [oracle.masks_from_logits(l)[0] for l in ref_logits]
+    res = [segment(x[i:i + 1]) for i in range(n_frames)]
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    ref_logits = np.concatenate(ref_logits); ref_masks = np.concatenate(ref_masks)
+    ref_logits = np.concatenate([r[0] for r in res]); ref_masks = np.concatenate([r[1] for r in res])
     mask, logits = gpu_model.segment(torch.from_numpy(x).cuda(), return_logits=True)
     torch.cuda.synchronize()
     err = float(np.abs(logits.cpu().numpy() - ref_logits).max())
@@ -80,67 +170,142 @@ def cpu_baseline(sd, syn, C, H, W, n_frames, gpu_model, torch):
     margin = oracle.top2_margin(ref_logits)
     base = {"value": n_frames / dt, "unit": "frames/s", "cores": int(best_nt), "kind": "port",
             "sample": f"{n_frames} frames of {C}-class {H}x{W}, batch 1 per call, torch {torch.__version__} CPU fp32 "
-                      f"(oracle/unetpp_oracle.py torch_forward + softmax/argmax), host cpu_count={os.cpu_count()}, "
+                      f"(oracle/unetpp_oracle.py {fwd.__name__} + softmax/argmax), host cpu_count={os.cpu_count()}, "
                       f"threads tried (frames/s): " + ", ".join(f"{k}:{v:.2f}" for k, v in sorted(trials.items()))}
     parity = {"frames": n_frames, "max_abs_logit_err": err, "mask_flips": int(flips.sum()),
               "mask_pixels": int(flips.size),
-              "flips_outside_near_ties": int((flips & (margin > 2 * err + 1e-7)).sum()), "logit_tol": 1e-3}
+              "flips_outside_near_ties": int((flips & (margin > 2 * err + 1e-7)).sum()), "logit_tol": 1e-3,
+              "range_status": int(gpu_model.status())}
     return base, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--precision", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--micro-batch", type=int, default=0)
-    ap.add_argument("--streams", type=int, default=1)
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--no-fast-leg", action="store_true")
-    ap.add_argument("--no-e2e-leg", action="store_true", help="skip the PCIe-inclusive informational leg")
-    args = ap.parse_args()
+def measured_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes, but only from a file that was
+    recorded for THIS build (same source hash) and workload; otherwise None plus the reason."""
+    import glob
+    from unet_amd import _lib
+    want = _lib.source_hash()
+    seen = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        seen.append(f"{os.path.basename(path)}:{d.get('src_hash', 'untagged')}")
+        if d.get("src_hash") != want or d.get("workload") != workload_key:
+            continue
+        if kernel not in d.get("kernels", {}):
+            return None, f"profiles/{os.path.basename(path)} matches this build but has no kernel {kernel!r}"
+        return d["kernels"][kernel]["hbm_bytes_per_launch"], (
+            f"profiles/{os.path.basename(path)} (src:{want}): (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
+    return None, f"no profiles/*_pmc_traffic.json recorded for build src:{want}, workload {workload_key} (have: {', '.join(seen[:4]) or 'none'})"
 
+
+class _NoEngine:
+    """Stand-in for the engine in `--no-engine` runs (CPU rehearsal of the launcher / collective control flow under
+    tests/test_bench_launcher.py).  It computes nothing; lines produced with it say so and carry value = null."""
+    def __init__(self, B, H, W):
+        import torch
+        self._mask = torch.zeros((B, H, W), dtype=torch.uint8)
+
+    def segment(self, x, return_logits=False):
+        time.sleep(0.002)
+        return self._mask
+
+    def status(self):
+        return 0
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args) -> int:
     import numpy as np
     import torch
     import torch.distributed as dist
-    from unet_amd import sharding, synthetic as syn
-    from unet_amd.nested_unet import NestedUNet
+    from unet_amd import _lib, sharding, synthetic as syn
+    from unet_amd.nested_unet import NestedUNet, SimpleUNet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
-    # one process per GPU; UNETPP_BENCH_SHARE_GPU=1 maps every rank onto the visible GPUs round-robin
-    # (rehearsal of the N>1 control flow on a 1-GPU box, together with UNETPP_DIST_BACKEND=gloo)
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev if os.environ.get("UNETPP_BENCH_SHARE_GPU") else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device(f"cuda:{dev_index}")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment", file=sys.stderr)
+        return 2
+    dry = args.no_engine
+    if dry and os.environ.get("UNETPP_BENCH_FAIL_RANK") == str(rank):     # launcher test: a rank that dies at start-up
+        print(f"bench.py: rank {rank} failing on request (UNETPP_BENCH_FAIL_RANK)", file=sys.stderr)
+        return 3
     backend = os.environ.get("UNETPP_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+    if dry:
+        dev = torch.device("cpu"); dev_index = -1
+        backend = "gloo"
+    else:
+        if not torch.cuda.is_available():
+            print("bench.py needs a HIP device: the engine has no CPU fallback", file=sys.stderr)
+            return 2
+        # one process per GPU; UNETPP_BENCH_SHARE_GPU=1 maps every rank onto the visible GPUs round-robin
+        # (rehearsal of the N>1 control flow on a 1-GPU box, together with UNETPP_DIST_BACKEND=gloo)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and not os.environ.get("UNETPP_BENCH_SHARE_GPU"):
+            print(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible)", file=sys.stderr)
+            return 2
+        dev_index = local_rank % ndev
+        torch.cuda.set_device(dev_index)
+        dev = torch.device(f"cuda:{dev_index}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    C, H, W, B = args.classes, args.height, args.width, args.batch
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(v):
+        if world == 1:
+            return float(v)
+        t = torch.tensor([v], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    arch, C, H, W, B = args.arch, args.classes, args.height, args.width, args.batch
     ds = C == 3
-    sd = syn.make_state_dict(C, 3, ds, 2) if rank == 0 else None
+    if arch == "nested":
+        sd = syn.make_state_dict(C, 3, ds, 2) if rank == 0 else None
+    else:
+        sd = syn.make_simple_state_dict(C, 3, 0) if rank == 0 else None
+    bcast = {"bytes": 0, "ms": None}
 
-    def make_model(precision):
-        m = NestedUNet(C, deep_supervision=ds, precision=precision, max_batch=B, max_hw=(H, W),
-                       micro_batch=args.micro_batch, streams=args.streams).to(dev)
+    def make_model(precision, timed_bcast=False):
+        if dry:
+            return _NoEngine(B, H, W)
+        if arch == "nested":
+            m = NestedUNet(C, deep_supervision=ds, precision=precision, max_batch=B, max_hw=(H, W),
+                           micro_batch=args.micro_batch, streams=args.streams).to(dev)
+        else:
+            m = SimpleUNet(C, 3, precision=precision, max_batch=B, max_hw=(H, W), micro_batch=args.micro_batch,
+                           streams=args.streams).to(dev)
         if world > 1:
             m._ensure_engine(B, H, W)
-            sharding.load_replicated(m, sd, C)           # RCCL broadcast of the weight blob from rank 0
+            barrier(); sync()                                   # the communicator exists before the timed broadcast
+            t0 = time.perf_counter()
+            blob = sharding.load_replicated(m, sd)              # RCCL broadcast of the weight blob from rank 0
+            sync()
+            if timed_bcast:
+                bcast["bytes"] = int(blob.numel()); bcast["ms"] = (time.perf_counter() - t0) * 1e3
         else:
             m.load_state_dict(sd, strict=True)
         return m.eval()
@@ -153,98 +318,106 @@ def main():
     def timed(model, steps, warmup, profile):
         for _ in range(warmup):
             model.segment(x)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sync(); barrier(); sync()
         if profile:
             model.profile(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             model.segment(x)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+        own = time.perf_counter() - t0                  # this rank alone, before waiting for the others
+        barrier(); sync()
         dt = time.perf_counter() - t0
         recs = model.profile_read() if profile else []
         if profile:
             model.profile(False)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, recs
+        return max_over_ranks(dt), own, recs
 
-    model = make_model(args.precision)
-    dt, recs = timed(model, args.steps, args.warmup, profile=True)
+    if world > 1:
+        barrier()                                       # first collective: sets the communicator up, untimed
+    model = make_model(args.precision, timed_bcast=True)
+    dt, own_dt, _ = timed(model, args.steps, args.warmup, profile=False)      # `value`: no per-launch events in the timed region
     fps = B * world * args.steps / dt
+    gflop = algorithmic_gflop(arch, C, H, W)
 
-    # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
-    agg = {}
-    for name, ms, fl, by in recs:
-        k = name.split("|")[-1]
-        a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
-        a[0] += ms; a[1] += fl; a[2] += by; a[3] += 1
-    dom = max(agg.items(), key=lambda kv: kv[1][0]) if agg else None
-    roofline = None
-    pmc = {}
-    try:   # HBM traffic per launch from the committed rocprofv3 --pmc passes (profiles/README.md), if present
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-        if files:
-            pmc = json.load(open(files[-1]))["kernels"]
-            pmc_src = os.path.basename(files[-1])
-    except Exception:
-        pmc = {}
-    if dom:
-        k, (ms, fl, by, cnt) = dom
-        tf = fl / (ms * 1e-3) / 1e12
-        mfma_mult = 3.0 if args.precision == "exact" else 1.0      # exact mode issues 3 MFMAs per product
-        traffic = pmc[k]["hbm_bytes_per_launch"] if (k in pmc and args.precision == "exact" and (C, H, W, B) == (3, 512, 512, 16)) else None
-        roofline = {"bound": "mfma", "kernel": k, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_source": (f"profiles/{pmc_src}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes"
-                                       if traffic is not None else None),
-                    "algorithmic_bytes_per_launch": by / cnt,
-                    "mfma_issued_tflops": tf * mfma_mult, "mfma_issued_frac": tf * mfma_mult / MFMA_F16_PEAK_TFLOPS,
-                    "avg_launch_ms": ms / cnt, "launches": cnt,
-                    "algorithmic_gflop_per_launch": fl / cnt / 1e9,
-                    "algorithmic_hbm_gbs": by / (ms * 1e-3) / 1e9,
-                    "time_share": ms / sum(v[0] for v in agg.values())}
+    # ---- roofline of the dominant kernel: a second, short loop with one HIP event per launch boundary, recorded on
+    # the launch stream by the engine (unetpp_profile_*); its per-step time is reported next to the un-profiled one
+    roofline, agg, prof_ms = None, {}, None
+    if not dry:
+        psteps = max(2, min(args.steps, 10))
+        pdt, _, recs = timed(model, psteps, 1, profile=True)
+        prof_ms = pdt / psteps * 1e3
+        for name, ms, fl, by in recs:
+            k = name.split("|")[-1]
+            a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
+            a[0] += ms; a[1] += fl; a[2] += by; a[3] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][0]) if agg else None
+        if dom:
+            k, (ms, fl, by, cnt) = dom
+            tf = fl / (ms * 1e-3) / 1e12
+            mfma_mult = 3.0 if args.precision == "exact" else 1.0      # exact mode issues 3 MFMAs per product
+            wkey = f"{arch}-c{C}-{H}x{W}-b{B}-{args.precision}"
+            traffic, tsrc = measured_traffic(k, wkey)
+            roofline = {"bound": "mfma", "kernel": k, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                        "algorithmic_bytes_per_launch": by / cnt,
+                        "mfma_issued_tflops": tf * mfma_mult, "mfma_issued_frac": tf * mfma_mult / MFMA_F16_PEAK_TFLOPS,
+                        "avg_launch_ms": ms / cnt, "launches": cnt, "profiled_steps": psteps,
+                        "algorithmic_gflop_per_launch": fl / cnt / 1e9,
+                        "algorithmic_hbm_gbs": by / (ms * 1e-3) / 1e9,
+                        "time_share": ms / sum(v[0] for v in agg.values()),
+                        "ms_per_step_with_events": prof_ms}
 
+    name = "UNet++" if arch == "nested" else "SimpleUNet"
     out = {
-        "metric": "frames/sec 512x512 3-class UNet++ inference; mask vs CPU reference" if (C, H, W) == (3, 512, 512)
-                  else f"frames/sec {H}x{W} {C}-class UNet++ inference",
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "frames/sec 512x512 3-class UNet++ inference; mask vs CPU reference" if (arch, C, H, W) == ("nested", 3, 512, 512)
+                  else f"frames/sec {H}x{W} {C}-class {name} inference",
+        "value": None if dry else fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16" if args.precision == "fast" else "f16 (MFMA operands split hi+lo, 3 MFMAs per product, f32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": f"UNet++ {C}-class {H}x{W} batch={B}/GPU fp16-MFMA on {world} MI355X, synthetic frames, "
+        "data": "synthetic" if not dry else "none (--no-engine control-flow rehearsal: nothing was computed)",
+        "config": {"workload": f"{name} {C}-class {H}x{W} batch={B}/GPU fp16-MFMA on {world} MI355X, synthetic frames, "
                                f"f32 NCHW in HBM -> uint8 mask in HBM",
-                   "precision": args.precision, "frames_per_gpu": B, "global_batch": B * world,
+                   "arch": arch, "precision": args.precision, "frames_per_gpu": B, "global_batch": B * world,
                    "micro_batch": args.micro_batch or B, "parallelism": f"frame-sharded x{world}, weights replicated (RCCL bcast)"},
-        "whole_net": {"gflop_per_frame": algorithmic_gflop(C, H, W),
-                      "achieved_tflops": fps * algorithmic_gflop(C, H, W) / 1e3,
-                      "frac_of_f16_mfma_peak": fps * algorithmic_gflop(C, H, W) / 1e3 / (MFMA_F16_PEAK_TFLOPS * world)},
+        "whole_net": {"gflop_per_frame": gflop, "achieved_tflops": fps * gflop / 1e3,
+                      "frac_of_f16_mfma_peak": fps * gflop / 1e3 / (MFMA_F16_PEAK_TFLOPS * world)},
         "roofline": roofline,
+        "build": _lib.load().unetpp_version().decode() if not dry else "no-engine",
     }
-    if rank == 0:
-        out["kernels"] = {k: {"ms_per_step": v[0] / args.steps, "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] else 0.0,
-                              "alg_gbs": (v[2] / (v[0] * 1e-3) / 1e9) if v[0] else 0.0, "launches_per_step": v[3] / args.steps}
+
+    # ---- multi-GPU bookkeeping: what really ran where (every rank contributes, rank 0 prints)
+    per_rank = gather({"rank": rank, "device": dev_index, "pid": os.getpid(),
+                       "frames_per_s": B * args.steps / own_dt, "frames": [lo, hi]})
+    if world > 1:
+        rates = [p["frames_per_s"] for p in per_rank]
+        out["distributed"] = {
+            "backend": dist.get_backend(), "rccl_world_size" if backend == "nccl" else "world_size": dist.get_world_size(),
+            "launched_by": "bench.py" if os.environ.get("UNETPP_BENCH_LAUNCHED") else "external launcher",
+            "devices": [p["device"] for p in per_rank], "pids": [p["pid"] for p in per_rank],
+            "frame_shards": [p["frames"] for p in per_rank],
+            "per_rank_frames_per_s": {"min": min(rates), "max": max(rates), "all": rates},
+            "weight_broadcast": {"bytes": bcast["bytes"], "ms": max_over_ranks(bcast["ms"] or 0.0),
+                                 "collectives_in_timed_region": 0},
+        }
+    if rank == 0 and agg:
+        out["kernels"] = {k: {"ms_per_step": v[0] / roofline["profiled_steps"], "tflops": (v[1] / (v[0] * 1e-3) / 1e12) if v[0] else 0.0,
+                              "alg_gbs": (v[2] / (v[0] * 1e-3) / 1e9) if v[0] else 0.0,
+                              "launches_per_step": v[3] / roofline["profiled_steps"]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
 
     # ---- CPU baseline + parity of the measured mode on the same frames (rank 0, N=1 only)
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
-        base, parity = cpu_baseline(sd, syn, C, H, W, args.cpu_frames, model, torch)
+    if rank == 0 and world == 1 and args.cpu_frames > 0 and not dry:
+        base, parity = cpu_baseline(sd, syn, arch, C, H, W, args.cpu_frames, model, torch)
         out["cpu_baseline"] = base
         out["parity"] = parity
     else:
         out["cpu_baseline"] = None
 
     # ---- informational: the PCIe-inclusive rate (never `value`): pinned uint8 BGR frames -> H2D -> engine (BGR->RGB,
-    # /255 fused) -> uint8 masks -> D2H into pinned memory, two engines on two streams so copies overlap compute
-    if not args.no_e2e_leg and world == 1:
+    # /255 fused) -> uint8 masks -> D2H into pinned memory, two engines on two streams so copies overlap compute.
+    # With N ranks every rank feeds its own GPU at the same time (what decides >= 6x at 8 GPUs is this host side).
+    if not args.no_e2e_leg and not dry:
         ma, mb = model, make_model(args.precision)
         eng = [ma, mb]
         st = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
@@ -259,35 +432,74 @@ def main():
                 h_out[k].copy_(eng[k].segment(d_in[k]), non_blocking=True)               # D2H
         for i in range(max(2, args.warmup)):
             e2e_step(i)
-        torch.cuda.synchronize()
+        sync(); barrier(); sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
             e2e_step(i)
-        torch.cuda.synchronize()
-        dte = time.perf_counter() - t0
-        out["end_to_end"] = {"value": B * args.steps / dte, "unit": "frames/s", "ms_per_step": dte / args.steps * 1e3,
-                             "path": "pinned uint8 BGR frames (0.79 MB/frame) H2D -> engine -> uint8 masks (0.26 MB/frame) D2H, "
-                                     "2 engines on 2 streams; informational, not `value`",
-                             "mask_equals_resident_path": bool(torch.equal(h_out[0], ma.segment(x).cpu()))}
+        sync()
+        own_e = time.perf_counter() - t0
+        barrier()
+        dte = max_over_ranks(time.perf_counter() - t0)
+        same = bool(torch.equal(h_out[0], ma.segment(x).cpu()))
+        e_rates = gather({"fps": B * args.steps / own_e, "same": same})
+        out["end_to_end"] = {"value": B * world * args.steps / dte, "unit": "frames/s", "ms_per_step": dte / args.steps * 1e3,
+                             "path": "pinned uint8 BGR frames (0.79 MB/frame at 512x512) H2D -> engine -> uint8 masks D2H, "
+                                     "2 engines on 2 streams per rank; informational, not `value`",
+                             "per_rank_frames_per_s": {"min": min(r["fps"] for r in e_rates), "max": max(r["fps"] for r in e_rates)},
+                             "mask_equals_resident_path": all(r["same"] for r in e_rates)}
         del mb, eng, d_in
 
     # ---- informational second leg: the other precision mode on the same workload
-    if not args.no_fast_leg and world == 1:
+    if not args.no_fast_leg and world == 1 and not dry:
         other = "fast" if args.precision == "exact" else "exact"
         del model
         m2 = make_model(other)
-        dt2, _ = timed(m2, args.steps, args.warmup, profile=False)
+        dt2, _, _ = timed(m2, args.steps, args.warmup, profile=False)
         leg = {"precision": other, "value": B * args.steps / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3}
         if rank == 0 and args.cpu_frames > 0:
-            _, p2 = cpu_baseline(sd, syn, C, H, W, min(args.cpu_frames, 2), m2, torch)
+            _, p2 = cpu_baseline(sd, syn, arch, C, H, W, min(args.cpu_frames, 2), m2, torch)
             leg["parity"] = p2
         out["other_precision"] = leg
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 16)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--classes", type=int, default=None)
+    ap.add_argument("--arch", default="nested", choices=["nested", "simple"],
+                    help="nested = NestedUNet / UNet++ (the BASELINE metric); simple = SimpleUNet (SURVEY 8(f) row 3)")
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-fast-leg", action="store_true")
+    ap.add_argument("--no-e2e-leg", action="store_true", help="skip the PCIe-inclusive informational leg")
+    ap.add_argument("--no-engine", action="store_true",
+                    help="control-flow rehearsal on CPU (gloo, no GPU, nothing computed, value = null): launcher tests only")
+    args = ap.parse_args()
+    simple = args.arch == "simple"
+    args.batch = args.batch or 16
+    args.height = args.height or (256 if simple else 512)
+    args.width = args.width or (256 if simple else 512)
+    args.classes = args.classes or (7 if simple else 3)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -12,7 +12,13 @@
  * unetpp_forward() is asynchronous on `stream` and never synchronises.  One engine per device;
  * an engine is not thread-safe, independent engines are.  The caller owns all I/O buffers; the
  * library owns packed weights and the activation workspace and never keeps a caller pointer.
- * Every call makes the engine's device the calling thread's current HIP device (hipSetDevice) and leaves it so.
+ * Every call runs with the engine's device current and restores the calling thread's previous HIP device before
+ * it returns.  One thread at a time per engine: the engine keeps per-call state (event pools, resize tables).
+ *
+ * Value range.  Activations live in HBM as fp16 planes (hi, or hi + lo in EXACT mode), so an activation (or a
+ * float32 input value) beyond +-65504 is clamped and a NaN does not propagate the way it does in the fp32
+ * reference (src/models/unetpp.py:23-26, src/models/simple_unet.py:94-128).  Neither happens silently: the
+ * kernel that narrows such a value sets a sticky flag, see unetpp_status().
  */
 #ifndef UNETPP_H
 #define UNETPP_H
@@ -114,6 +120,18 @@ int unetpp_load_weights_device(unetpp_engine* e, const void* dev_blob, size_t by
 int unetpp_forward(unetpp_engine* e, const void* dev_input, int in_format, int batch, int h, int w,
                    float* dev_logits, uint8_t* dev_mask, uint8_t* dev_cable, uint8_t* dev_tape,
                    void* stream);
+
+/* ---- value-range status -------------------------------------------------------------------------
+ * Sticky flags set by the kernels of any forward since creation (or since the last clearing read):
+ *   UNETPP_STATUS_OVERFLOW  a conv / transposed-conv output or a float32 input value exceeded the fp16
+ *                           range and was clamped to +-65504: results differ from the fp32 reference
+ *   UNETPP_STATUS_NAN       a NaN in a float32 input, or a non-finite weight / bias in a loaded blob (the only ways
+ *                           a NaN can reach an accumulator: fp16 operands cannot overflow fp32 sums); the reference
+ *                           would carry it to its logits, this engine replaces it (clamp -> +-65504, ReLU -> 0)
+ * unetpp_status synchronises the device (hipDeviceSynchronize), copies the flags to *flags and, with
+ * clear != 0, resets them.  0 = every value since the last clear was representable. */
+enum { UNETPP_STATUS_OVERFLOW = 1, UNETPP_STATUS_NAN = 2 };
+int unetpp_status(unetpp_engine* e, uint32_t* flags, int clear);
 
 /* ---- probability outputs and thresholded class rules -------------------------
  * Half of the reference's frame loops do not take a plain argmax: they compute

@@ -28,10 +28,10 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 
 def _load_synthetic():
-    spec = importlib.util.spec_from_file_location("synthetic", os.path.join(ROOT, "unet-_amd", "synthetic.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    return m
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from unet_amd import synthetic
+    return synthetic
 
 
 def _import_reference():

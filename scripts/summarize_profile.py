@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output into the small files committed under profiles/.
 
-usage: summarize_profile.py TAG KERNEL_STATS_CSV [FETCH_COUNTER_CSV WRITE_COUNTER_CSV]
+usage: summarize_profile.py TAG KERNEL_STATS_CSV [FETCH_COUNTER_CSV WRITE_COUNTER_CSV [WORKLOAD]]
+
+WORKLOAD names what was profiled in bench.py's notation (default nested-c3-512x512-b16-exact); together with the
+source hash of the library that ran (unet_amd._lib.source_hash(), the same tree this script is run from on the GPU
+box) it lets bench.py refuse HBM-traffic numbers that were recorded for another build or workload.
 
 Writes profiles/TAG_kernel_stats.csv (copy of --kernel-trace --stats) and, when the two
 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are given, profiles/TAG_pmc_traffic.json with per-kernel
@@ -11,6 +15,7 @@ on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads, so reads
 import collections, csv, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def short(name):
@@ -52,7 +57,9 @@ def main():
             res[k] = {"launches_sampled": n, "fetch_size_kib_per_launch_raw": fk / n,
                       "read_bytes_per_launch": 2.0 * fk / n * 1024, "write_bytes_per_launch": wk / max(n2, 1) * 1024,
                       "hbm_bytes_per_launch": (2.0 * fk / n + wk / max(n2, 1)) * 1024}
-        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB units; reads = 2 x FETCH_SIZE "
+        from unet_amd import _lib
+        workload = sys.argv[5] if len(sys.argv) >= 6 else "nested-c3-512x512-b16-exact"
+        json.dump({"src_hash": _lib.source_hash(), "workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB units; reads = 2 x FETCH_SIZE "
                            "(gfx950 wide-read correction, MI355X_MICROARCH.md §HBM); averages over all launches of a kernel "
                            "(layers of different shapes share a kernel instantiation)", "kernels": res},
                   open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)

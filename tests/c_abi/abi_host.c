@@ -78,6 +78,11 @@ int main(int argc, char** argv) {
   if (unetpp_forward(e, d_in, UNETPP_IN_U8_NHWC_BGR, 1, H - 8, W, NULL, (uint8_t*)d_mask, NULL, NULL, NULL) == 0 ||
       unetpp_last_error(e)[0] == 0) { fprintf(stderr, "bad shape was accepted\n"); return 1; }
 
+  /* every value of this run fitted the fp16 activation planes (unetpp_status synchronises and reads the sticky flags) */
+  uint32_t flags = 99;
+  CHECK(unetpp_status(e, &flags, 1));
+  if (flags != 0) { fprintf(stderr, "range status %u after an ordinary forward\n", (unsigned)flags); return 1; }
+
   float* logits = (float*)malloc(px * C * sizeof(float));
   uint8_t* bytes = (uint8_t*)malloc(px * 3);
   if (hipMemcpy(logits, d_logits, px * C * sizeof(float), D2H) || hipMemcpy(bytes, d_mask, px, D2H) ||

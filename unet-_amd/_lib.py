@@ -5,7 +5,9 @@ device is present, every entry point raises."""
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
+import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -19,11 +21,12 @@ ABI_SYMBOLS = [
     "unetpp_create", "unetpp_destroy", "unetpp_last_error", "unetpp_version", "unetpp_weights_blob_bytes",
     "unetpp_weights_blob_bytes_arch",
     "unetpp_load_weights", "unetpp_load_weights_device", "unetpp_forward", "unetpp_forward_ex", "unetpp_mask_stats", "unetpp_workspace_bytes",
-    "unetpp_resize_linear_u8", "unetpp_resize_nearest_roi_u8",
+    "unetpp_resize_linear_u8", "unetpp_resize_nearest_roi_u8", "unetpp_status",
     "unetpp_profile_enable", "unetpp_profile_count", "unetpp_profile_read", "unetpp_profile_name",
     "unetpp_profile_work", "unetpp_debug_read", "unetpp_debug_keep_intermediates",
 ]
 
+STATUS_OVERFLOW, STATUS_NAN = 1, 2
 PREC_EXACT, PREC_FAST = 0, 1
 ARCH_NESTED, ARCH_SIMPLE = 0, 1
 IN_F32_NCHW, IN_U8_NHWC_BGR = 0, 1
@@ -45,22 +48,49 @@ class Outputs(ctypes.Structure):
                 ("ct_margin", ctypes.c_float)]
 
 
+def source_hash() -> str:
+    """Digest of every file the library is compiled from; baked into the binary (unetpp_version() ends in
+    'src:<hash>') so that a .so built from other sources is recognised wherever it travels."""
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def built_hash(path: str = LIB_PATH):
+    """The 'src:' tag of a built library, read from the file (no dlopen), or None."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(b"(gfx950) src:")
+    if i < 0:
+        return None
+    tag = blob[i + 13:i + 13 + 16]
+    return tag.decode("ascii", "replace")
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return built_hash() != source_hash()
+
+
+def _hipcc():
+    cand = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return cand if os.path.exists(cand) else shutil.which("hipcc")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> unet-_amd/libunetpp_hip.so (cross-compiles without a GPU)."""
     if not force and not _stale():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = _hipcc()
+    if not hipcc:
+        raise RuntimeError("hipcc not found: cannot build libunetpp_hip.so")
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"      # several ranks may build at once: write aside, then rename atomically
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DUNETPP_SRC_HASH="{source_hash()}"',
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd).replace(tmp, LIB_PATH), flush=True)
     try:
@@ -79,9 +109,12 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+    if _stale():
+        # missing, or built from other sources than the tree holds (the .so is git-ignored but travels to the GPU
+        # box): rebuild when a compiler is at hand, otherwise refuse -- never run kernels that do not match the tree
+        what = "is missing" if not os.path.exists(LIB_PATH) else f"was built from other sources (src:{built_hash()}, tree {source_hash()})"
+        if not build_if_missing or not _hipcc():
+            raise RuntimeError(f"{LIB_PATH} {what}: build it with __graft_entry__.build(); there is no CPU fallback")
         build()
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -100,6 +133,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_resize_nearest_roi_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
     lib.unetpp_resize_nearest_roi_u8.restype = ci
     lib.unetpp_workspace_bytes.argtypes = [vp]; lib.unetpp_workspace_bytes.restype = cs
+    lib.unetpp_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ci]; lib.unetpp_status.restype = ci
     lib.unetpp_profile_enable.argtypes = [vp, ci]; lib.unetpp_profile_enable.restype = ci
     lib.unetpp_profile_count.argtypes = [vp]; lib.unetpp_profile_count.restype = ci
     lib.unetpp_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ci]; lib.unetpp_profile_read.restype = ci
@@ -109,5 +143,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_debug_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), cs]
     lib.unetpp_debug_read.restype = ctypes.c_longlong
     lib.unetpp_debug_keep_intermediates.argtypes = [vp, ci]; lib.unetpp_debug_keep_intermediates.restype = ci
+    if not lib.unetpp_version().decode().endswith("src:" + source_hash()):
+        raise RuntimeError(f"{LIB_PATH} reports {lib.unetpp_version().decode()!r}, tree is src:{source_hash()}")
     _lib = lib
     return lib

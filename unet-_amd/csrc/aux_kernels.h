@@ -10,11 +10,18 @@ namespace unetpp {
 // Per-output-channel power-of-two weight scaling: scaled weights have max |w| in [2^13, 2^14), so
 // the fp16 `lo` plane of a split weight stays in the normal range (22 significant bits overall).
 // scale_out[co] = 2^-k is applied to the fp32 accumulator in the conv epilogue (exact).
-__global__ void weight_scale_kernel(const float* __restrict__ w, int per_co, float* __restrict__ mult_out,
-                                    float* __restrict__ scale_out) {
+// A non-finite weight or bias (the only way a NaN can get into an accumulator) sets ST_NAN in the engine's status.
+__global__ void weight_scale_kernel(const float* __restrict__ w, int per_co, const float* __restrict__ bias,
+                                    float* __restrict__ mult_out, float* __restrict__ scale_out, unsigned* __restrict__ status) {
   const int co = blockIdx.x;
   float m = 0.f;
-  for (int i = threadIdx.x; i < per_co; i += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)co * per_co + i]));
+  bool bad = threadIdx.x == 0 && !(fabsf(bias[co]) <= 3.0e38f);
+  for (int i = threadIdx.x; i < per_co; i += blockDim.x) {
+    const float x = fabsf(w[(size_t)co * per_co + i]);
+    bad |= !(x <= 3.0e38f);
+    m = fmaxf(m, x);
+  }
+  if (bad) atomicOr(status, ST_NAN);
   __shared__ float red[256];
   red[threadIdx.x] = m;
   __syncthreads();
@@ -67,7 +74,7 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
 //   fmt 1: uint8 NHWC BGR: RGB = BGR reversed, /255.0f   (preprocess_image, infer_two_stage_burr.py:122-127)
 template <int P>
 __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N, int H, int W,
-                                     half_t* __restrict__ out) {
+                                     half_t* __restrict__ out, unsigned* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * H * W;
   if (i >= total) return;
@@ -83,11 +90,19 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
     v[1] = __fdiv_rn((float)b[1], 255.0f);
     v[2] = __fdiv_rn((float)b[0], 255.0f);
   }
+  // a float32 input outside the fp16 range (or a NaN) cannot enter the hi/lo planes unchanged: report it
+  const bool beyond = !(fabsf(v[0]) <= F16_MAX) || !(fabsf(v[1]) <= F16_MAX) || !(fabsf(v[2]) <= F16_MAX);
+  if (__builtin_amdgcn_ballot_w64(beyond)) {
+    const bool nan = v[0] != v[0] || v[1] != v[1] || v[2] != v[2];
+    const unsigned long long bn = __builtin_amdgcn_ballot_w64(nan), bo = __builtin_amdgcn_ballot_w64(beyond && !nan);
+    if (beyond && status) atomicOr(status, (bn ? ST_NAN : 0u) | (bo ? ST_OVERFLOW : 0u));
+  }
   half8 hi, lo;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { hi[e] = (half_t)0.f; lo[e] = (half_t)0.f; }
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
+    v[e] = __builtin_amdgcn_fmed3f(v[e], -F16_MAX, F16_MAX);
     half_t h = (half_t)v[e];
     hi[e] = h;
     lo[e] = (half_t)(v[e] - (float)h);

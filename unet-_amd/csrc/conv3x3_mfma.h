@@ -69,7 +69,24 @@ struct ConvArgs {
   float* probs;          // [N][C][H][W] fp32 or nullptr
   int rule;              // UNETPP_RULE_*
   float t_cable, t_tape, bg_margin, ct_margin;
+  unsigned* status;      // engine's sticky range flags (ST_*), see range_flag
 };
+
+// ---- range status -------------------------------------------------------------------------------------
+// Activations are stored as fp16 hi + lo, so a value beyond +-65504 cannot be represented: it is clamped, and a
+// NaN does not survive the ReLU (v_max_f32 returns the other operand).  The fp32 reference
+// (src/models/unetpp.py:23-26, simple_unet.py:94-128) has neither limit, so every kernel that narrows a value
+// reports it in the engine's sticky status word (include/unetpp.h: unetpp_status).  NaNs can only enter through
+// the input (convert_input_kernel checks every value) or through non-finite weights (weight_scale_kernel /
+// convt_scale_kernel check them at load time): finite fp16 operands cannot overflow the fp32 accumulator.  The
+// conv epilogues therefore only watch the fp16 ceiling: half a VALU instruction per value (v_max3_f32).
+constexpr unsigned ST_OVERFLOW = 1u, ST_NAN = 2u;
+constexpr float F16_MAX = 65504.0f;
+__device__ __forceinline__ void range_flag(unsigned* status, bool out_of_range, bool is_nan) {
+  const unsigned long long bn = __builtin_amdgcn_ballot_w64(is_nan);
+  const unsigned long long bo = __builtin_amdgcn_ballot_w64(out_of_range && !is_nan);
+  if ((threadIdx.x & 63) == 0 && status) atomicOr(status, (bn ? ST_NAN : 0u) | (bo ? ST_OVERFLOW : 0u));
+}
 
 // cable/tape decision for one pixel from its class probabilities (p0 = background, p1 = cable, p2 = tape)
 //   1 thresholded_argmax              infer_video_3class_best.py:56-83, infer_video_strict.py:36-63
@@ -124,7 +141,7 @@ struct ConvCfg {
 };
 
 __device__ __forceinline__ void split_f16(float v, half_t& hi, half_t& lo) {
-  v = fminf(v, 65504.0f);
+  v = fminf(v, F16_MAX);
   hi = (half_t)v;
   lo = (half_t)(v - (float)hi);
 }
@@ -167,7 +184,9 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
-      const float v0 = fminf(v[4 * q + 2 * w2], 65504.0f), v1 = fminf(v[4 * q + 2 * w2 + 1], 65504.0f);
+      // clamp to the fp16 range (both signs: the transposed conv has no ReLU); the caller has reported it (range_flag)
+      const float v0 = __builtin_amdgcn_fmed3f(v[4 * q + 2 * w2], -F16_MAX, F16_MAX);
+      const float v1 = __builtin_amdgcn_fmed3f(v[4 * q + 2 * w2 + 1], -F16_MAX, F16_MAX);
       const half_t h0 = (half_t)v0, h1 = (half_t)v1;
       half2v ph = {h0, h1};
       wh[q][w2] = __builtin_bit_cast(unsigned, ph);
@@ -462,13 +481,18 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
       for (int j = 0; j < NW; ++j) {
         const int cbase = cur_ct * BN + j * 32;
         float v[MW][16];
+        float vmax = 0.f;                                  // largest activation of this lane's part of the tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float2 sb = sb_lds[co];
 #pragma unroll
           for (int m = 0; m < MW; ++m) v[m][r] = fmaxf(acc[m][j][r] * sb.x + sb.y, 0.f);
+          vmax = (MW == 2) ? fmaxf(fmaxf(vmax, v[0][r]), v[MW - 1][r]) : fmaxf(vmax, v[0][r]);     // v_max3_f32
         }
+        // fp16 planes end at 65504: the store below clamps, and says so in the engine's sticky status word.  (A NaN
+        // cannot arise here: inputs are sanitised by convert_input, weights are checked when they are loaded.)
+        if (!HEAD && __builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
         if (!HEAD) {
 #pragma unroll
           for (int m = 0; m < MW; ++m) {

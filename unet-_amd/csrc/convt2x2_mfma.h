@@ -20,6 +20,7 @@ struct ConvTArgs {
   const float* bias;     // [Cout]
   half_t* out;           // [N][Cout/16][2H][2W][P][16]
   int N, H, W, Cin, Cout;
+  unsigned* status;      // engine's sticky range flags (conv3x3_mfma.h: range_flag)
 };
 
 template <int P>
@@ -124,8 +125,12 @@ __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
       const int pc = min(p, HW - 1);
       const int y = pc / a.W, x = pc - y * a.W;
       float v[16];
+      float vmax = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[pt][j][r] * sc[r] + bi[r];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) vmax = fmaxf(fmaxf(vmax, fabsf(v[r])), fabsf(v[r + 1]));
+      if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * oblk + ((size_t)(2 * y + dy) * W2 + (2 * x + dx)) * (P * 16);
       pack_store_octets<P>(v, dst, oblk, ok, h);
     }
@@ -133,11 +138,17 @@ __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
 }
 
 // per-output-channel weight scale for a ConvTranspose2d weight [Cin][Cout][2][2]
-__global__ void convt_scale_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ mult_out,
-                                   float* __restrict__ scale_out) {
+__global__ void convt_scale_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ bias,
+                                   float* __restrict__ mult_out, float* __restrict__ scale_out, unsigned* __restrict__ status) {
   const int co = blockIdx.x;
   float m = 0.f;
-  for (int i = threadIdx.x; i < Cin * 4; i += blockDim.x) m = fmaxf(m, fabsf(w[((size_t)(i >> 2) * Cout + co) * 4 + (i & 3)]));
+  bool bad = threadIdx.x == 0 && !(fabsf(bias[co]) <= 3.0e38f);
+  for (int i = threadIdx.x; i < Cin * 4; i += blockDim.x) {
+    const float x = fabsf(w[((size_t)(i >> 2) * Cout + co) * 4 + (i & 3)]);
+    bad |= !(x <= 3.0e38f);
+    m = fmaxf(m, x);
+  }
+  if (bad) atomicOr(status, ST_NAN);          // non-finite weights: the reference would carry NaN to its logits
   __shared__ float red[256];
   red[threadIdx.x] = m;
   __syncthreads();

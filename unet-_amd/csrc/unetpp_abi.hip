@@ -20,7 +20,10 @@
 #include <cstring>
 #include <string>
 #include <map>
+#include <mutex>
+#include <set>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/unetpp.h"
@@ -125,6 +128,7 @@ struct unetpp_engine {
   hipEvent_t ev_start = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
   // frame glue: per-axis resize tables on the device, keyed by (kind, n_src, n_dst); kind 0 = linear, 1 = nearest
   std::map<std::tuple<int, int, int>, void*> resize_tabs;
+  unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
 };
 
 namespace {
@@ -146,6 +150,24 @@ int fail(unetpp_engine* e, int code, const char* fmt, ...) {
   } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Every entry point runs with the engine's device current and puts the caller's device back on return, so that a
+// single-process multi-GPU program (torch, another engine) is not redirected by a call into this library.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t st = hipSuccess;
+  explicit DeviceScope(int dev) {
+    st = hipGetDevice(&prev);
+    if (st == hipSuccess && prev != dev) { st = hipSetDevice(dev); switched = st == hipSuccess; }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ENTER_DEVICE(e)                          \
+  DeviceScope _dev_scope((e)->cfg.device);       \
+  if (_dev_scope.st != hipSuccess) return fail(e, UNETPP_E_HIP, "hipSetDevice(%d): %s", (e)->cfg.device, hipGetErrorString(_dev_scope.st))
 
 // payload floats of the canonical blob and number of layers in it
 size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
@@ -182,6 +204,19 @@ size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
 // ---- conv dispatch ---------------------------------------------------------------------------
 struct LaunchCtx { int device; int num_cus; };   // per engine: one process may drive engines on several devices
 
+// The conv kernels take more dynamic LDS than the 64 KiB default: raise the function's limit to the whole 160 KiB
+// once per (device, kernel).  The attribute is process-wide state of the HIP runtime and engines may be driven
+// from several threads, so the bookkeeping is locked and the value is the same constant for everybody.
+hipError_t allow_full_lds(const void* kernel, int device) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({device, kernel})) return hipSuccess;
+  hipError_t st = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (st == hipSuccess) done.insert({device, kernel});
+  return st;
+}
+
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
 hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>()>;
@@ -191,9 +226,8 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
   dim3 grid((unsigned)std::min(total, cx.num_cus * per_cu));
   auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD>;
-  static int attr_lds[64] = {};       // the attribute is per device: remember what each one was given
-  int& have = attr_lds[cx.device & 63];
-  if (have < lds) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); have = lds; }
+  hipError_t st = allow_full_lds((const void*)k, cx.device);
+  if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
 }
@@ -260,8 +294,9 @@ struct Launcher {
     ProfRec* r = nullptr;
     auto new_event = [&]() {
       if ((size_t)e->ev_used >= e->evpool.size()) {
-        hipEvent_t ev;
-        (void)hipEventCreate(&ev);
+        hipEvent_t ev = nullptr;
+        hipError_t es = hipEventCreate(&ev);
+        if (es != hipSuccess) { rc = fail(e, UNETPP_E_HIP, "hipEventCreate: %s", hipGetErrorString(es)); return -1; }
         e->evpool.push_back(ev);
       }
       return e->ev_used++;
@@ -274,6 +309,7 @@ struct Launcher {
         r->ev0 = e->prof_prev_ev;
       } else {
         r->ev0 = new_event();
+        if (r->ev0 < 0) { --e->prof_used; return; }
         (void)hipEventRecord(e->evpool[r->ev0], s);
       }
     }
@@ -281,6 +317,7 @@ struct Launcher {
     if (st == hipSuccess) st = hipGetLastError();
     if (r) {
       r->ev1 = new_event();
+      if (r->ev1 < 0) { --e->prof_used; e->prof_prev_ev = -1; return; }
       (void)hipEventRecord(e->evpool[r->ev1], s);
       e->prof_prev_ev = r->ev1; e->prof_prev_stream = s;
     }
@@ -409,7 +446,11 @@ void build_simple(unetpp_engine* e, Builder& b) {
 
 extern "C" {
 
-const char* unetpp_version(void) { return "unetpp-hip 0.2.0 (gfx950)"; }
+#ifndef UNETPP_SRC_HASH
+#define UNETPP_SRC_HASH "unknown"
+#endif
+// "src:<hash>" = digest of the sources this binary was built from (unet-_amd/_lib.py compares it with the tree)
+const char* unetpp_version(void) { return "unetpp-hip 0.3.0 (gfx950) src:" UNETPP_SRC_HASH; }
 
 const char* unetpp_last_error(const unetpp_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -443,7 +484,8 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, UNETPP_E_HIP, "no HIP device available: this engine has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, UNETPP_E_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
-  HIP_TRY(nullptr, hipSetDevice(cfg->device));
+  DeviceScope dev_scope(cfg->device);
+  if (dev_scope.st != hipSuccess) return fail(nullptr, UNETPP_E_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(dev_scope.st));
 
   unetpp_engine* e = new unetpp_engine();
   {
@@ -484,13 +526,19 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     tsc[i] = total; total += align_up(T.cout * sizeof(float), 256);
     tmu[i] = total; total += align_up(T.cout * sizeof(float), 256);
   }
+  const size_t status_off = total; total += 256;
   hipError_t st = hipMalloc((void**)&e->arena, total);
+  if (st == hipSuccess) {
+    st = hipMemset(e->arena + status_off, 0, 256);
+    if (st != hipSuccess) { (void)hipFree(e->arena); e->arena = nullptr; }
+  }
   if (st != hipSuccess) {
     std::string m = hipGetErrorString(st);
     delete e;
     return fail(nullptr, UNETPP_E_HIP, "hipMalloc(%zu bytes): %s", total, m.c_str());
   }
   e->arena_bytes = total;
+  e->d_status = (unsigned*)(e->arena + status_off);
   e->blob = (float*)(e->arena + blob_off);
   for (size_t i = 0; i < e->convs.size(); ++i) {
     e->convs[i].wpk = (half_t*)(e->arena + wpk_off[i]);
@@ -521,7 +569,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
 
 void unetpp_destroy(unetpp_engine* e) {
   if (!e) return;
-  (void)hipSetDevice(e->cfg.device);
+  DeviceScope dev_scope(e->cfg.device);
   for (auto ev : e->evpool) (void)hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) { if (e->streams[i]) (void)hipStreamDestroy(e->streams[i]); if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]); }
   if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -536,7 +584,7 @@ static int repack(unetpp_engine* e, hipStream_t s) {
   const int P = e->P;
   for (auto& L : e->convs) {
     const float* w = e->blob + L.w_off;
-    hipLaunchKernelGGL(weight_scale_kernel, dim3(L.cout), dim3(256), 0, s, w, L.cin_real * 9, L.mult, L.scale);
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(L.cout), dim3(256), 0, s, w, L.cin_real * 9, e->blob + L.b_off, L.mult, L.scale, e->d_status);
     const int BN = 32 * L.NW;
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
@@ -544,7 +592,7 @@ static int repack(unetpp_engine* e, hipStream_t s) {
   }
   for (auto& T : e->convts) {
     const float* w = e->blob + T.w_off;
-    hipLaunchKernelGGL(convt_scale_kernel, dim3(T.cout), dim3(256), 0, s, w, T.cin, T.cout, T.mult, T.scale);
+    hipLaunchKernelGGL(convt_scale_kernel, dim3(T.cout), dim3(256), 0, s, w, T.cin, T.cout, e->blob + T.b_off, T.mult, T.scale, e->d_status);
     long long units = (long long)(4 * T.cout / 32) * (T.cin / 16) * P * 64;
     hipLaunchKernelGGL(convt_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, T.mult, T.cin, T.cout, P,
                        T.wpk, units);
@@ -567,7 +615,7 @@ static int check_header(unetpp_engine* e, const uint32_t* h, size_t bytes) {
 
 int unetpp_load_weights(unetpp_engine* e, const void* host_blob, size_t bytes) {
   if (!e || !host_blob) return fail(e, UNETPP_E_INVALID, "null argument");
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   if (bytes < 32) return fail(e, UNETPP_E_INVALID, "weight blob too small");
   int rc = check_header(e, (const uint32_t*)host_blob, bytes);
   if (rc) return rc;
@@ -580,7 +628,7 @@ int unetpp_load_weights(unetpp_engine* e, const void* host_blob, size_t bytes) {
 
 int unetpp_load_weights_device(unetpp_engine* e, const void* dev_blob, size_t bytes, void* stream) {
   if (!e || !dev_blob) return fail(e, UNETPP_E_INVALID, "null argument");
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   if (bytes < 32) return fail(e, UNETPP_E_INVALID, "weight blob too small");
   uint32_t h[8];
   hipStream_t s = (hipStream_t)stream;
@@ -618,13 +666,32 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
   if (h < mult || w < mult || h % mult || w % mult)
     return fail(e, UNETPP_E_INVALID, "Sizes of tensors must match: H=%d W=%d must be positive multiples of %d", h, w, mult);
   if (h > e->cfg.max_h || w > e->cfg.max_w) return fail(e, UNETPP_E_INVALID, "shape %dx%d exceeds engine maximum %dx%d", h, w, e->cfg.max_h, e->cfg.max_w);
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   hipStream_t user_stream = (hipStream_t)stream;
   hipStream_t s = user_stream;
   const int P = e->P, C = e->cfg.num_classes;
   const bool multi = e->nstreams > 1 && batch > e->mb;
+  // join: the caller's stream continues after every internal stream has drained.  It runs on EVERY exit after the
+  // fork, failures included: the caller may free or reuse its output buffers on its stream right after an error
+  // return, and kernels already queued on the internal streams still write to them.
+  struct Join {
+    unetpp_engine* e; hipStream_t user; bool armed = false;
+    hipError_t run() {
+      if (!armed) return hipSuccess;
+      armed = false;
+      hipError_t first = hipSuccess;
+      for (int i = 0; i < e->nstreams; ++i) {
+        hipError_t r = hipEventRecord(e->ev_done[i], e->streams[i]);
+        if (r == hipSuccess) r = hipStreamWaitEvent(user, e->ev_done[i], 0);
+        if (r != hipSuccess) { (void)hipStreamSynchronize(e->streams[i]); if (first == hipSuccess) first = r; }
+      }
+      return first;
+    }
+    ~Join() { (void)run(); }
+  } join{e, user_stream};
   if (multi) {   // fork: the internal streams start after everything already queued on the caller's stream
     HIP_TRY(e, hipEventRecord(e->ev_start, user_stream));
+    join.armed = true;
     for (int i = 0; i < e->nstreams; ++i) HIP_TRY(e, hipStreamWaitEvent(e->streams[i], e->ev_start, 0));
   }
   e->last_b = batch; e->last_h = h; e->last_w = w;
@@ -653,8 +720,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         size_t total = (size_t)nb * hw;
         double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
         Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8));
-          else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8));
+          if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
+          else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
           return hipSuccess;
         });
       } else if (op.kind == OP_CONV) {
@@ -668,6 +735,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.wpk = L.wpk; a.scale = L.scale; a.bias = e->blob + L.b_off; a.out = tp(L.out);
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
+        a.status = e->d_status;
         const int mw = small_grid_rows(L, e->num_cus, nb, H, W, head);
         const int TH = L.WAVES * mw;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
@@ -710,6 +778,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         const int H = h >> T.lvl, W = w >> T.lvl;
         a.in = tp(T.in); a.wpk = T.wpk; a.scale = T.scale; a.bias = e->blob + T.b_off; a.out = tp(T.out);
         a.N = nb; a.H = H; a.W = W; a.Cin = T.cin; a.Cout = T.cout;
+        a.status = e->d_status;
         double px = (double)nb * H * W;
         double flops = 2.0 * px * T.cin * T.cout * 4;
         double bytes = px * P * 2.0 * (T.cin + 4.0 * T.cout) + 4.0 * T.cin * T.cout * 2.0 * P;
@@ -737,13 +806,20 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     }
     if (Lx.rc) return Lx.rc;
   }
-  if (multi) {   // join: the caller's stream continues after every internal stream has drained
-    for (int i = 0; i < e->nstreams; ++i) {
-      HIP_TRY(e, hipEventRecord(e->ev_done[i], e->streams[i]));
-      HIP_TRY(e, hipStreamWaitEvent(user_stream, e->ev_done[i], 0));
-    }
-  }
+  HIP_TRY(e, join.run());
   return Lx.rc;
+}
+
+int unetpp_status(unetpp_engine* e, uint32_t* flags, int clear) {
+  if (!e) return UNETPP_E_INVALID;
+  if (!flags) return fail(e, UNETPP_E_INVALID, "flags is NULL");
+  ENTER_DEVICE(e);
+  HIP_TRY(e, hipDeviceSynchronize());      // every forward queued so far has set its bits
+  unsigned v = 0;
+  HIP_TRY(e, hipMemcpy(&v, e->d_status, sizeof v, hipMemcpyDeviceToHost));
+  if (clear && v) HIP_TRY(e, hipMemset(e->d_status, 0, sizeof v));
+  *flags = v;
+  return UNETPP_OK;
 }
 
 int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int h, int w, uint32_t* dev_counts,
@@ -751,7 +827,7 @@ int unetpp_mask_stats(unetpp_engine* e, const uint8_t* dev_mask, int batch, int 
   if (!e) return UNETPP_E_INVALID;
   if (!dev_mask || !dev_counts || !dev_row_min || !dev_row_max) return fail(e, UNETPP_E_INVALID, "null argument");
   if (batch < 1 || h < 1 || w < 1) return fail(e, UNETPP_E_INVALID, "bad shape %dx%dx%d", batch, h, w);
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   hipStream_t s = (hipStream_t)stream;
   const int C = e->cfg.num_classes;
   HIP_TRY(e, hipMemsetAsync(dev_counts, 0, (size_t)batch * C * sizeof(uint32_t), s));
@@ -819,7 +895,7 @@ int unetpp_resize_linear_u8(unetpp_engine* e, const uint8_t* dev_src, int batch,
     return fail(e, UNETPP_E_INVALID, "bad resize shape %dx%dx%dx%d -> %dx%d", batch, src_h, src_w, channels, dst_h, dst_w);
   if (batch > 65535 || dst_h > 65535 || (size_t)src_h * src_w * channels > 0x7fffffffULL)
     return fail(e, UNETPP_E_INVALID, "resize shape too large");
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   void *xt = nullptr, *yt = nullptr;
   int rc = resize_table(e, 0, src_w, dst_w, &xt); if (rc) return rc;
   rc = resize_table(e, 0, src_h, dst_h, &yt); if (rc) return rc;
@@ -839,7 +915,7 @@ int unetpp_resize_nearest_roi_u8(unetpp_engine* e, const uint8_t* dev_src, int b
   if (batch > 65535 || dst_h > 65535) return fail(e, UNETPP_E_INVALID, "resize shape too large");
   if (x1 < 0 || y1 < 0 || x2 < 0 || y2 < 0) return fail(e, UNETPP_E_INVALID, "negative ROI bound (%d, %d, %d, %d)", x1, y1, x2, y2);
   if (match_class > 255) return fail(e, UNETPP_E_INVALID, "match_class %d out of range", match_class);
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   void *xo = nullptr, *yo = nullptr;
   int rc = resize_table(e, 1, src_w, dst_w, &xo); if (rc) return rc;
   rc = resize_table(e, 1, src_h, dst_h, &yo); if (rc) return rc;
@@ -862,6 +938,7 @@ int unetpp_profile_enable(unetpp_engine* e, int on) {
 int unetpp_profile_count(const unetpp_engine* e) { return e ? e->prof_used : 0; }
 int unetpp_profile_read(unetpp_engine* e, float* ms_out, int n) {
   if (!e || !ms_out) return UNETPP_E_INVALID;
+  ENTER_DEVICE(e);
   int m = std::min(n, e->prof_used);
   for (int i = 0; i < m; ++i) {
     HIP_TRY(e, hipEventSynchronize(e->evpool[e->prof[i].ev1]));
@@ -897,7 +974,7 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
   if (e->cfg.arch == UNETPP_ARCH_NESTED && tid == e->t_head_in && !e->keep_all)
     return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
-  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  ENTER_DEVICE(e);
   int nb = e->last_b % e->mb == 0 ? std::min(e->mb, e->last_b) : e->last_b % e->mb;
   const int H = e->last_h >> t->lvl, W = e->last_w >> t->lvl;
   size_t total = (size_t)nb * t->C * H * W;

@@ -25,7 +25,7 @@ class NestedUNet:
     _SIZE_MULTIPLE = 16
     def __init__(self, num_classes: int, input_channels: int = 3, deep_supervision: bool = True,
                  pretrained_encoder: bool = False, *, precision: str = "exact", max_batch: int = 16,
-                 max_hw=(512, 512), micro_batch: int = 0, streams: int = 1) -> None:
+                 max_hw=(512, 512), micro_batch: int = 0, streams: int = 1, check_range: bool = False) -> None:
         if pretrained_encoder:
             # unetpp.py:52-65 swaps in a torchvision ResNet50 and downloads ImageNet weights; no
             # north-star caller uses it (infer_two_stage_burr.py:214) and there is no network here.
@@ -43,6 +43,8 @@ class NestedUNet:
         self._max_hw = (int(max_hw[0]), int(max_hw[1]))
         self._micro_batch = int(micro_batch)
         self._streams = int(streams)
+        self._keep_all = False
+        self._check_range = bool(check_range)      # debug aid: synchronise and raise after a forward that left the fp16 range
         self._device_index: Optional[int] = None
         self._handle = None
         self._blob: Optional[np.ndarray] = None      # canonical weights (host copy, re-uploaded if the engine is rebuilt)
@@ -129,6 +131,8 @@ class NestedUNet:
             msg = lib.unetpp_last_error(None)
             raise RuntimeError(f"unetpp_create failed ({rc}): {msg.decode() if msg else ''}")
         self._handle = handle
+        if self._keep_all:
+            lib.unetpp_debug_keep_intermediates(self._handle, 1)
         if self._blob is not None:
             self._upload()
 
@@ -137,6 +141,12 @@ class NestedUNet:
         rc = lib.unetpp_load_weights(self._handle, self._blob.ctypes.data_as(ctypes.c_void_p), self._blob.nbytes)
         if rc != 0:
             raise RuntimeError(self._err(rc))
+
+    def _check_and_build_blob(self, state_dict):
+        """strict key check + canonical blob of this architecture (rank 0 of sharding.load_replicated)."""
+        state_dict = packing.unwrap_checkpoint(state_dict)
+        packing.check_state_dict(state_dict, self.num_classes, self.input_channels, self.deep_supervision, strict=True)
+        return packing.build_blob(state_dict, self.num_classes, self.input_channels)
 
     def load_weights_from_device_blob(self, blob_tensor):
         """After an RCCL broadcast: `blob_tensor` is a uint8 CUDA tensor holding the canonical blob."""
@@ -193,9 +203,34 @@ class NestedUNet:
         rc = _lib.load().unetpp_forward_ex(self._handle, p(x), fmt, b, h, w, ctypes.byref(outs), stream)
         if rc != 0:
             raise RuntimeError(self._err(rc))
+        if self._check_range:
+            self.raise_on_range_error()
         if want_probs:
             return logits, mask, cable, tape, probs
         return logits, mask, cable, tape
+
+    # ------------------------------------------------------------------ value-range status
+    def status(self, clear: bool = False) -> int:
+        """Sticky range flags of the engine (include/unetpp.h: UNETPP_STATUS_OVERFLOW = 1, UNETPP_STATUS_NAN = 2):
+        set when an activation or input value did not fit the fp16 planes the engine stores activations in — the
+        fp32 reference (unetpp.py:23-26) has no such limit, so a non-zero status means the results may differ from
+        it.  Synchronises the device."""
+        if self._handle is None:
+            return 0
+        flags = ctypes.c_uint32(0)
+        rc = _lib.load().unetpp_status(self._handle, ctypes.byref(flags), 1 if clear else 0)
+        if rc != 0:
+            raise RuntimeError(self._err(rc))
+        return int(flags.value)
+
+    def raise_on_range_error(self):
+        """RuntimeError if any forward since the last check left the fp16 range (clears the flags)."""
+        flags = self.status(clear=True)
+        if flags:
+            what = [n for bit, n in ((_lib.STATUS_OVERFLOW, "activation/input beyond +-65504 clamped"),
+                                     (_lib.STATUS_NAN, "NaN encountered")) if flags & bit]
+            raise RuntimeError("unetpp: value range of the fp16 activation planes exceeded (" + "; ".join(what) +
+                               "): results differ from the fp32 reference")
 
     def forward(self, x):
         """NestedUNet.forward in eval mode (unetpp.py:93-135): float32 [B,3,H,W] -> float32 logits [B,C,H,W]."""
@@ -314,7 +349,9 @@ class NestedUNet:
 
     def debug_keep_intermediates(self, on: bool = True):
         """Materialise x0_4 and run the head unfused (needed before debug_activation('x0_4'))."""
-        _lib.load().unetpp_debug_keep_intermediates(self._handle, 1 if on else 0)
+        self._keep_all = bool(on)                    # also applied to an engine that is (re)built later
+        if self._handle is not None:
+            _lib.load().unetpp_debug_keep_intermediates(self._handle, 1 if on else 0)
 
     def _node_shape(self, name: str):
         lvl = int(name[1])
@@ -341,9 +378,9 @@ class SimpleUNet(NestedUNet):
     _SIZE_MULTIPLE = 8
 
     def __init__(self, num_classes: int = 7, num_channels: int = 3, *, precision: str = "exact", max_batch: int = 16,
-                 max_hw=(256, 256), micro_batch: int = 0, streams: int = 1) -> None:
+                 max_hw=(256, 256), micro_batch: int = 0, streams: int = 1, check_range: bool = False) -> None:
         super().__init__(num_classes, num_channels, False, False, precision=precision, max_batch=max_batch,
-                         max_hw=max_hw, micro_batch=micro_batch, streams=streams)
+                         max_hw=max_hw, micro_batch=micro_batch, streams=streams, check_range=check_range)
         self.num_channels = int(num_channels)
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -356,6 +393,11 @@ class SimpleUNet(NestedUNet):
         if self._handle is not None:
             self._upload()
         return missing, unexpected
+
+    def _check_and_build_blob(self, state_dict):
+        state_dict = packing.unwrap_checkpoint(state_dict)
+        packing.check_simple_state_dict(state_dict, self.num_classes, self.num_channels, strict=True)
+        return packing.build_simple_blob(state_dict, self.num_classes, self.num_channels)
 
     def _node_shape(self, name: str):
         lvl = int(name[3]) - 1                      # 'enc1'..'enc4', 'dec1'..'dec3'

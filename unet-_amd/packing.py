@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .synthetic import conv_blocks, simple_unet_manifest, state_dict_manifest
+from .manifest import conv_blocks, simple_unet_manifest, state_dict_manifest
 
 BN_EPS = 1e-5
 BLOB_MAGIC = 0x50504E55  # 'UNPP'

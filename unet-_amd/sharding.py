@@ -32,18 +32,19 @@ def broadcast_blob(blob_np, nbytes: int, device, src: int = 0):
     return t.to(device)
 
 
-def load_replicated(model, state_dict_or_none, num_classes: int, in_channels: int = 3, src: int = 0):
+def load_replicated(model, state_dict_or_none, num_classes: int = None, in_channels: int = 3, src: int = 0):
     """Rank `src` folds/packs its state_dict; every rank receives the blob by broadcast and uploads it
-    with unetpp_load_weights_device (no host round trip on the receivers)."""
+    with unetpp_load_weights_device (no host round trip on the receivers).  Works for both architectures
+    (NestedUNet and SimpleUNet): the blob size and builder are the model's own."""
     import torch
     import torch.distributed as dist
-    from . import _lib, packing
-    nbytes = int(_lib.load().unetpp_weights_blob_bytes(num_classes, in_channels))
+    from . import _lib
+    if num_classes is not None and int(num_classes) != model.num_classes:
+        raise ValueError(f"num_classes={num_classes} but the model was built for {model.num_classes}")
+    nbytes = int(_lib.load().unetpp_weights_blob_bytes_arch(model._ARCH, model.num_classes, in_channels))
     blob = None
     if dist.get_rank() == src:
-        sd = packing.unwrap_checkpoint(state_dict_or_none)
-        packing.check_state_dict(sd, num_classes, in_channels, model.deep_supervision, strict=True)
-        blob = packing.build_blob(sd, num_classes, in_channels)
+        blob = model._check_and_build_blob(state_dict_or_none)
     dev = torch.device(f"cuda:{model._device_index}")
     t = broadcast_blob(blob, nbytes, dev, src)
     model.load_weights_from_device_blob(t)
