@@ -117,9 +117,8 @@ def launch_ranks(args) -> int:
     if out0 is None:
         out0 = procs[0].stdout.read() if procs[0].stdout else ""
     codes = [p.poll() if p.poll() is not None else -9 for p in procs]
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+    for line in (out0 or "").splitlines():     # the JSON line goes to stdout, library chatter ("[Gloo] Rank 0 ...") to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     worst = max((abs(c) for c in codes), default=0)
     if worst:
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)

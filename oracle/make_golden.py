@@ -171,6 +171,47 @@ def main():
                           f"class_hist={np.bincount(pred.ravel(), minlength=C).tolist()} near_ties(<1e-3)={len(tie_margin)} "
                           f"min_margin={m.min():.3e}")
 
+    # ---- BASELINE config 2 at its stated batch (16 frames, both frame kinds): masks, near-tie list, subsampled logits
+    # and, for frames 0-1, every node x0_0 ... x0_4 sampled at seeded random positions (per-layer localisation at a
+    # size where the deep layers span many 16x32 tiles)
+    tag, C, ds, wseed, B, H, W, kinds, fseed = ("b_c3_512x512_b16", 3, True, 2, 16, 512, 512, ("smooth", "uniform"), 1234)
+    frames = np.stack([syn.make_frame_u8(H, W, i, kinds[i % len(kinds)], fseed) for i in range(B)])
+    sd, logits, pred, _ = run_reference(NestedUNet, syn, C, ds, wseed, frames, False)
+    _, _, _, inter = run_reference(NestedUNet, syn, C, ds, wseed, frames[:2], True)
+    m = margin_of(logits)
+    payload = dict(num_classes=C, deep_supervision=ds, wseed=wseed, B=B, H=H, W=W, kinds=np.array(kinds), fseed=fseed,
+                   frames_sha=sha(frames), mask=pred, logits_sub8=logits[:, :, ::8, ::8].astype(np.float32),
+                   logits_sha=sha(logits.astype(np.float32)), mask_sha=sha(pred),
+                   tie_idx=np.argwhere(m < 1e-3).astype(np.int32), tie_margin=m[m < 1e-3].astype(np.float32),
+                   class_hist=np.stack([np.bincount(pred[i].ravel(), minlength=C) for i in range(B)]))
+    prng = np.random.Generator(np.random.PCG64(99))
+    for name, t in inter.items():
+        lvl = int(name[1])
+        h, w = H >> lvl, W >> lvl
+        npos = 256 if lvl <= 1 else 64
+        ys = prng.integers(0, h, npos).astype(np.int32); xs = prng.integers(0, w, npos).astype(np.int32)
+        ys[:4] = (0, 0, h - 1, h - 1); xs[:4] = (0, w - 1, 0, w - 1)            # the four corners always
+        payload["p_" + name] = np.stack([ys, xs], 1)
+        payload["t_" + name] = t[:, :, ys, xs].astype(np.float32)              # [2, C, npos]
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **payload)
+    meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] "
+                      f"class_hist={np.bincount(pred.ravel(), minlength=C).tolist()} near_ties(<1e-3)={int((m < 1e-3).sum())} "
+                      f"min_margin={m.min():.3e}")
+
+    # ---- BASELINE config 5 (3-class 1024x1024): one frame through the reference, the same sparse payload
+    tag, C, ds, wseed, B, H, W, kinds, fseed = ("b_c3_1024x1024", 3, True, 2, 1, 1024, 1024, ("smooth",), 1234)
+    frames = np.stack([syn.make_frame_u8(H, W, 0, "smooth", fseed)])
+    sd, logits, pred, _ = run_reference(NestedUNet, syn, C, ds, wseed, frames, False)
+    m = margin_of(logits)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"),
+                        num_classes=C, deep_supervision=ds, wseed=wseed, B=B, H=H, W=W, kinds=np.array(kinds), fseed=fseed,
+                        frames_sha=sha(frames), mask=pred, logits_sub8=logits[:, :, ::8, ::8].astype(np.float32),
+                        logits_sha=sha(logits.astype(np.float32)), mask_sha=sha(pred),
+                        tie_idx=np.argwhere(m < 1e-3).astype(np.int32), tie_margin=m[m < 1e-3].astype(np.float32))
+    meta_lines.append(f"{tag}: logits[{logits.min():.3f},{logits.max():.3f}] "
+                      f"class_hist={np.bincount(pred.ravel(), minlength=C).tolist()} near_ties(<1e-3)={int((m < 1e-3).sum())} "
+                      f"min_margin={m.min():.3e}")
+
     # ---- SimpleUNet: the reference class on our synthetic state_dict
     from src.models.simple_unet import SimpleUNet
     simple_cases = [("su_c7_32x48", 7, 0, 1, 32, 48, "smooth", 31, True), ("su_c7_256x256", 7, 0, 1, 256, 256, "smooth", 32, False),

@@ -21,8 +21,8 @@ def run(args, extra_env=None, timeout=300):
 def test_self_launch_two_ranks_gloo():
     r = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-engine", "--batch", "4", "--height", "32", "--width", "32"])
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                   # one line, from rank 0 only
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{")      # stdout = the one JSON line of rank 0, nothing else
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["value"] is None and "no-engine" in d["data"]   # a rehearsal never reports a rate

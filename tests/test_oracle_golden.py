@@ -228,3 +228,23 @@ def test_cv2_nearest_restatement_and_roi_clip(oracle):
     cable, tape = oracle.postprocess_masks_np(np.array([[0, 1], [2, 1]], np.uint8), (4, 4), (0, 0, 4, 2))
     assert cable.tolist() == [[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]]
     assert tape.tolist() == [[0] * 4] * 4
+
+
+def test_config2_b16_and_config5_fixtures_pin_the_oracle(oracle, syn):
+    """The two full-batch fixtures: the oracle reproduces the reference's subsampled logits, masks (up to listed
+    near-ties) and sampled intermediates on a subset of frames (the whole 16 would take a minute here)."""
+    g = load_golden("b_c3_512x512_b16")
+    kinds = [str(k) for k in g["kinds"]]
+    idx = [0, 1, 9]
+    frames = np.stack([syn.make_frame_u8(512, 512, i, kinds[i % len(kinds)], int(g["fseed"])) for i in idx])
+    sd = syn.make_state_dict(3, 3, True, int(g["wseed"]))
+    logits, inter = oracle.torch_forward(sd, syn.frames_to_chw_f32(frames), return_intermediates=True)
+    np.testing.assert_allclose(logits[:, :, ::8, ::8], g["logits_sub8"][idx], rtol=0, atol=5e-6)
+    pred, _, _ = oracle.masks_from_logits(logits)
+    ties = {tuple(t) for t in g["tie_idx"].tolist()}
+    for j, i in enumerate(idx):
+        assert all((i, y, x) in ties for y, x in np.argwhere(pred[j] != g["mask"][i]).tolist())
+    for name in ("x0_0", "x1_0", "x2_0", "x3_0", "x4_0", "x3_1", "x2_2", "x1_3", "x0_4"):
+        ys, xs = g["p_" + name][:, 0], g["p_" + name][:, 1]
+        np.testing.assert_allclose(inter[name][:2][:, :, ys, xs], g["t_" + name], rtol=0, atol=5e-6, err_msg=name)
+    assert g["mask"].shape == (16, 512, 512) and sorted(set(kinds)) == ["smooth", "uniform"]
