@@ -110,7 +110,7 @@ __device__ __forceinline__ void apply_rule(int rule, float p0, float p1, float p
   }
 }
 
-template <int P, int KC, int NW, int MW, int WAVES, bool SINGLE = false>
+template <int P, int KC, int NW, int MW, int WAVES, bool SINGLE = false, bool UPF = false>
 struct ConvCfg {
   static constexpr int NT = WAVES * 64;
   static constexpr int TH = WAVES * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
@@ -133,7 +133,15 @@ struct ConvCfg {
   // It pays where HBM is not the limit anyway: the fused-head conv, which reads x0_4a and writes one byte per pixel
   // (265 -> 221 us); the other full-resolution convs already run at the HBM rate and stay double-buffered.
   static constexpr int STAGES = SINGLE ? 1 : 2;
-  static constexpr int LDS_BYTES = STAGES * BUF_BYTES;
+  // UPF (fused bilinear upsample, see the kernel): the low-res pixels one chunk of `up` channels is interpolated
+  // from -- at most TH/2+2 rows x 18 columns (checked for every tile origin and size up to 4096) of P*32-byte
+  // records -- staged by LDS-DMA two chunks ahead, double buffered.
+  static constexpr int LSH = TH / 2 + 2, LSW = TW / 2 + 2, LS_PX = LSH * LSW;
+  static constexpr int LS_REC = P * 32;                                   // bytes per low-res pixel and channel block
+  static constexpr int LS_PIECES = (LS_PX * LS_REC + 1023) / 1024;
+  static constexpr int LS_BYTES = UPF ? LS_PIECES * 1024 : 0;
+  static constexpr int LS_ITERS = (LS_PIECES + WAVES - 1) / WAVES;
+  static constexpr int LDS_BYTES = STAGES * BUF_BYTES + 2 * LS_BYTES;
   static constexpr int SLAB_PIECES = SLAB_BYTES / 1024;   // one LDS-DMA wave-instruction = 1 KiB
   static_assert(U == 2 || U == 4, "unit count per pixel");
   static_assert(SLAB_BYTES % 1024 == 0, "slab must be a whole number of 1 KiB DMA pieces");
@@ -223,10 +231,17 @@ constexpr int HEAD_FUSED_MAX_CLASSES = 8;   // the fused head keeps all logits i
 // the exact-mode fused-head kernel runs single-staged, two workgroups per CU (see ConvCfg::STAGES)
 template <int P, bool HEAD> constexpr bool conv_single_stage() { return HEAD && P == 2; }
 
-template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false>
+// UPF = fused bilinear upsample (reference unetpp.py:76,112-116: cat([skip, self.up(low)])): the second source `in1`
+// is then the LOW-resolution tensor [N][C1/16][H/2][W/2][P][16] itself; the loader interpolates each chunk's halo
+// image from it (align_corners=True: src = dst*(in-1)/(out-1), same arithmetic as upsample2x_kernel) instead of
+// fetching a materialised `up` tensor: per tile and chunk, <= 10 x 18 low-res pixel records arrive by LDS-DMA two
+// chunks ahead, and while chunk c multiplies, the waves build chunk c+1's halo image from them (VALU + ds_write
+// beside the MFMAs).  The `up` tensor is never written or read: -2.4 GB of the 12.7 GB step at level 0.
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false, bool UPF = false>
 __global__ __launch_bounds__(WAVES * 64, (conv_single_stage<P, HEAD>() ? 2 : 1))
 void conv3x3_bias_relu_kernel(ConvArgs a) {
-  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>()>;
+  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>(), UPF>;
+  static_assert(!UPF || (!POOL && !HEAD && KC == 16 && MW == 2 && !conv_single_stage<P, HEAD>()), "fused upsample: plain 16-row tiles only");
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
   constexpr int KG = C::KG, BN = C::BN, PPP = C::PPP;
   constexpr int ITERS = C::HALO_ITERS;
@@ -259,7 +274,8 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
   unsigned voff0[ITERS], voff1[ITERS];
   __amdgpu_buffer_rsrc_t rsrc0, rsrc1;
   const char* wsrc;
-  const unsigned img_bytes0 = (unsigned)(H * W * P * a.C0 * 2), img_bytes1 = (unsigned)(H * W * P * a.C1 * 2);
+  const unsigned img_bytes0 = (unsigned)(H * W * P * a.C0 * 2);
+  const unsigned img_bytes1 = (unsigned)((UPF ? (H >> 1) * (W >> 1) : H * W) * P * a.C1 * 2);
   int cur_n, cur_y0, cur_x0, cur_ct;
   auto decode = [&](int t, int& n, int& y0, int& x0, int& ct) {
     ct = t % a.nct;
@@ -274,7 +290,27 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
   // unused items carry an out-of-range offset and read back zeros — no branches in the K loop.
   const int cb0 = a.C0 < 16 ? a.C0 : 16;                        // channel block of source 0 (8 only for the input tensor)
   const unsigned plane_bytes0 = (unsigned)(H * W * P * cb0 * 2);   // one channel block of one image
-  const unsigned plane_bytes1 = (unsigned)(H * W * P * 16 * 2);
+  const int Hs = UPF ? (H >> 1) : H, Ws = UPF ? (W >> 1) : W;      // extent of source 1 (UPF: the low-res tensor)
+  const unsigned plane_bytes1 = (unsigned)(Hs * Ws * P * 16 * 2);
+  // ---- UPF state.  Interpolation items: one (halo pixel, channel octet) per thread and round; the halo pixel of an
+  // item never changes, its four low-res corners and weights are set up per tile.
+  constexpr int UP_ITEMS = C::NHALO * KG;
+  constexpr int UP_ROUNDS = UPF ? (UP_ITEMS + NT - 1) / NT : 0;
+  constexpr int LSR = UPF ? C::LS_ITERS : 1, UPR = UPF ? UP_ROUNDS : 1;
+  unsigned voffL[LSR];                       // LDS-DMA source offsets of this lane's low-res staging pieces
+  int up_o00[UPR], up_o01[UPR], up_o10[UPR]; // byte offsets of the corners (y0,x0), (y0,x1), (y1,x0) in the staging image
+  float up_lx1[UPR], up_ly0[UPR], up_ly1[UPR];
+  int up_dst[UPR];                           // byte offset of the item's hi octet in a halo image, -1 = no item
+  const float up_sh = Hs > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
+  const float up_sw = Ws > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f;
+  if (UPF) {
+#pragma unroll
+    for (int r = 0; r < UPR; ++r) {
+      const int i = tid + r * NT;
+      const int kg = i / C::NHALO, hp = i - kg * C::NHALO;
+      up_dst[r] = i < UP_ITEMS ? (hp / PPP) * 1024 + (kg * PPP + hp % PPP) * 16 : -1;
+    }
+  }
   auto setup_sources = [&](int n, int y0, int x0, int ct) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -288,9 +324,42 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
       voff1[it] = ok ? (unsigned)(k8 >> 4) * plane_bytes1 + (pix * 16 + (k8 & 15)) * 2u : OOB;
     }
     rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)n * H * W * P * a.C0), 0, (int)img_bytes0, 0x00020000);
-    rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 ? a.in1 + (size_t)n * H * W * P * a.C1 : a.in0), 0,
+    rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 ? a.in1 + (size_t)n * Hs * Ws * P * a.C1 : a.in0), 0,
                                               (int)(a.in1 ? img_bytes1 : 0u), 0x00020000);
     wsrc = (const char*)a.wpk + (size_t)ct * a.nchunks * C::SLAB_BYTES;
+    if (UPF) {
+      // first low-res row / column any halo pixel of this tile touches (halo pixels outside the image touch none)
+      const int ybase = (int)(up_sh * (float)max(y0 - 1, 0)), xbase = (int)(up_sw * (float)max(x0 - 1, 0));
+      constexpr int PXP = 1024 / C::LS_REC, PARTS = C::LS_REC / 16;      // pixels per 1 KiB piece, 16-byte parts per record
+#pragma unroll
+      for (int it = 0; it < LSR; ++it) {
+        const int lp = (wave + it * WAVES) * PXP + lane / PARTS;           // staged pixel (row-major LSH x LSW)
+        const int ly = lp / C::LSW, lx = lp - ly * C::LSW;
+        const int yy = min(ybase + ly, Hs - 1), xx = min(xbase + lx, Ws - 1);   // clamped: always a valid record
+        voffL[it] = lp < C::LS_PX ? (unsigned)((yy * Ws + xx) * C::LS_REC + (lane % PARTS) * 16) : OOB;
+      }
+#pragma unroll
+      for (int r = 0; r < UPR; ++r) {
+        const int i = tid + r * NT;
+        const int kg = i / C::NHALO, hp = i - kg * C::NHALO;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool inside = i < UP_ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        // align_corners=True source coordinates, exactly as upsample2x_kernel computes them
+        const float fy = up_sh * (float)max(gy, 0), fx = up_sw * (float)max(gx, 0);
+        const int yy0 = min((int)fy, Hs - 1), xx0 = min((int)fx, Ws - 1);
+        const int yy1 = yy0 + (yy0 < Hs - 1 ? 1 : 0), xx1 = xx0 + (xx0 < Ws - 1 ? 1 : 0);
+        const float ly1 = fminf(fmaxf(fy - (float)yy0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - (float)xx0, 0.f), 1.f);
+        const int ry0 = min(max(yy0 - ybase, 0), C::LSH - 1), ry1 = min(max(yy1 - ybase, 0), C::LSH - 1);
+        const int rx0 = min(max(xx0 - xbase, 0), C::LSW - 1), rx1 = min(max(xx1 - xbase, 0), C::LSW - 1);
+        up_o00[r] = (ry0 * C::LSW + rx0) * C::LS_REC + kg * 16;
+        up_o01[r] = (ry0 * C::LSW + rx1) * C::LS_REC + kg * 16;
+        up_o10[r] = (ry1 * C::LSW + rx0) * C::LS_REC + kg * 16;
+        up_lx1[r] = lx1;
+        up_ly0[r] = inside ? 1.f - ly1 : 0.f;           // zero padding of the convolution: both row weights 0
+        up_ly1[r] = inside ? ly1 : 0.f;
+      }
+    }
   };
 
   // halo piece `it` of this wave for chunk c, straight into the halo image at LDS byte offset `halo_off`:
@@ -301,7 +370,48 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
     const unsigned dst = lds_base + halo_off + piece * 1024;
     // scalar offset = first channel block of the chunk
     if (c < nch0) blds16(rsrc0, voff0[it], c * (KC / 16) * (int)plane_bytes0, dst);
-    else blds16(rsrc1, voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, dst);
+    else if (!UPF) blds16(rsrc1, voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, dst);
+  };
+  // UPF: staging piece `it` of this wave for up-chunk c -> staging buffer (c & 1)
+  const int ls_base = C::STAGES * C::BUF_BYTES;
+  auto ls_dma_one = [&](int c, int it) {
+    const int piece = wave + it * WAVES;
+    if (C::LS_PIECES % WAVES != 0 && piece >= C::LS_PIECES) return;
+    blds16(rsrc1, voffL[it], (c - nch0) * (int)plane_bytes1, lds_base + ls_base + (c & 1) * C::LS_BYTES + piece * 1024);
+  };
+  // UPF: item `r` of this thread: interpolate 8 channels of one halo pixel of up-chunk c from staging buffer (c & 1)
+  // into the halo image at `halo_off`.  x inside each row first, then y -- the order upsample2x_kernel uses.
+  auto up_item = [&](int c, int halo_off, int r) {
+    if (up_dst[r] < 0) return;
+    const char* ls = smem + ls_base + (c & 1) * C::LS_BYTES;
+    const int o11 = up_o10[r] + (up_o01[r] - up_o00[r]);
+    const half8 h00 = *(const half8*)(ls + up_o00[r]), h01 = *(const half8*)(ls + up_o01[r]);
+    const half8 h10 = *(const half8*)(ls + up_o10[r]), h11 = *(const half8*)(ls + o11);
+    half8 l00, l01, l10, l11;
+    if (P == 2) {
+      l00 = *(const half8*)(ls + up_o00[r] + 32); l01 = *(const half8*)(ls + up_o01[r] + 32);
+      l10 = *(const half8*)(ls + up_o10[r] + 32); l11 = *(const half8*)(ls + o11 + 32);
+    }
+    const float lx1 = up_lx1[r], lx0 = 1.f - lx1, ly0 = up_ly0[r], ly1 = up_ly1[r];
+    half8 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t0, t1;
+      if (P == 2) {
+        t0 = fmaf(lx1, (float)l01[e], fmaf(lx1, (float)h01[e], fmaf(lx0, (float)l00[e], lx0 * (float)h00[e])));
+        t1 = fmaf(lx1, (float)l11[e], fmaf(lx1, (float)h11[e], fmaf(lx0, (float)l10[e], lx0 * (float)h10[e])));
+      } else {
+        t0 = fmaf(lx1, (float)h01[e], lx0 * (float)h00[e]);
+        t1 = fmaf(lx1, (float)h11[e], lx0 * (float)h10[e]);
+      }
+      const float v = fmaf(ly1, t1, ly0 * t0);
+      const half_t hi = (half_t)v;
+      oh[e] = hi;
+      if (P == 2) ol[e] = (half_t)(v - (float)hi);
+    }
+    char* dst = smem + halo_off + up_dst[r];
+    *(half8*)dst = oh;
+    if (P == 2) *(half8*)(dst + KG * PPP * 16) = ol;
   };
   constexpr int DMA_PER_WAVE = (C::SLAB_PIECES + WAVES - 1) / WAVES;
   auto slab_dma_one = [&](int c, int slab_off, int p) {
@@ -449,6 +559,15 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
 #pragma unroll
           for (int k = st * DPS; k < (st + 1) * DPS; ++k)
             if (k < DMA_PER_WAVE) slab_dma_one(pc, nxt_slab, k);
+        }
+        if (UPF) {
+          // chunk c+2's low-res records (landed and published by the end-of-chunk wait + barrier of chunk c+1) ...
+          if (st < LSR && c + 2 < a.nchunks && c + 2 >= nch0) ls_dma_one(c + 2, st);
+          // ... and chunk c+1's halo image, one item round every UP_EVERY steps, between this chunk's MFMA steps.
+          // (Measured: the rounds do not overlap the matrix work of the SIMD's other wave even when the two waves
+          // take them at different steps -- all eight waves run in lock-step; see DESIGN.md.)
+          constexpr int UP_EVERY = NSTEPS / UPR;
+          if (st % UP_EVERY == 0 && st / UP_EVERY < UPR && !last && c + 1 >= nch0) up_item(c + 1, nxt_halo, st / UP_EVERY);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep prefetch + load issue ahead of this step's MFMAs
         run_mfma(fc);

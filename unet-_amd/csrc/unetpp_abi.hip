@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <map>
@@ -56,6 +57,7 @@ struct ConvLayer {
   int lvl = 0;
   int in = -1, in2 = -1, out = -1, pool = -1;   // tensor ids; in2: second source of the virtual concat
   bool do_pool = false;
+  bool upf = false;             // in2 is the LOW-resolution tensor: the loader does the bilinear x2 itself (no `up` tensor)
   size_t w_off = 0, b_off = 0;  // float offsets inside the canonical blob payload
   int KC = 16, NW = 1, MW = 2, WAVES = 8;
   int nchunks = 1;
@@ -217,15 +219,15 @@ hipError_t allow_full_lds(const void* kernel, int device) {
   return st;
 }
 
-template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD>
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD, bool UPF = false>
 hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) {
-  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>()>;
+  using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>(), UPF>;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   // persistent workgroups: as many as are resident at once, each walks tiles blockIdx, +grid, ...
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
   dim3 grid((unsigned)std::min(total, cx.num_cus * per_cu));
-  auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD>;
+  auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD, UPF>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
@@ -233,7 +235,11 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 }
 
 template <int P, int KC, int NW, int MW, int WAVES>
-hipError_t launch_conv_cfg(const LaunchCtx& cx, const ConvArgs& a, bool pool, bool head, hipStream_t s) {
+hipError_t launch_conv_cfg(const LaunchCtx& cx, const ConvArgs& a, bool pool, bool head, bool upf, hipStream_t s) {
+  if constexpr (NW == 1 && MW == 2 && KC == 16) {      // fused upsample: built for the narrow full-resolution tiles
+    if (upf) return (pool || head) ? hipErrorInvalidValue : launch_conv_k<P, KC, NW, MW, WAVES, false, false, true>(cx, a, s);
+  }
+  if (upf) return hipErrorInvalidValue;
   if constexpr (NW == 1) {
     if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(cx, a, s);
   }
@@ -247,7 +253,7 @@ hipError_t launch_conv_cfg(const LaunchCtx& cx, const ConvArgs& a, bool pool, bo
 // `mw` = rows per wave: the layer's own (2: 16-row tiles) or 1 (8-row tiles, see small_grid_rows)
 hipError_t launch_conv(const LaunchCtx& cx, int P, const ConvLayer& L, int mw, const ConvArgs& a, bool head, hipStream_t s) {
 #define CASE(p, kc, nw, mw_, wv) \
-  if (P == p && L.KC == kc && L.NW == nw && mw == mw_ && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw_, wv>(cx, a, L.do_pool, head, s);
+  if (P == p && L.KC == kc && L.NW == nw && mw == mw_ && L.WAVES == wv) return launch_conv_cfg<p, kc, nw, mw_, wv>(cx, a, L.do_pool, head, L.upf, s);
   CASE(1, 16, 1, 2, 8)
   CASE(1, 32, 2, 2, 8)
   CASE(1, 16, 2, 2, 8)
@@ -267,7 +273,7 @@ hipError_t launch_conv(const LaunchCtx& cx, int P, const ConvLayer& L, int mw, c
 // workgroups, each with half the matrix work per K-chunk.  Every output is still accumulated chunk by chunk, tap by
 // tap in the same order, so the result is bitwise the same whichever tile height ran (tested).
 int small_grid_rows(const ConvLayer& L, int num_cus, int nb, int H, int W, bool head) {
-  if (L.do_pool || head || L.NW == 1 || L.MW != 2) return L.MW;
+  if (L.do_pool || head || L.upf || L.NW == 1 || L.MW != 2) return L.MW;
   const int tiles = nb * ((W + 31) / 32) * ((H + 15) / 16) * (L.cout / (32 * L.NW));
   return tiles < num_cus ? 1 : L.MW;
 }
@@ -388,12 +394,18 @@ void build_nested(unetpp_engine* e, Builder& b) {
   for (int l = 3; l >= 0; --l) {
     char nm[32], tn[32];
     snprintf(tn, sizeof tn, "x%d_%d", l, 4 - l);
-    up[l] = b.tensor(std::string(tn) + "u", NB[l + 1], l);
+    const int low = l == 3 ? x[4] : d[l + 1];
+    // Level 0 (Cout = 32: narrow tiles, HBM co-bound): the decoder conv interpolates its `up` channels itself from
+    // the low-res tensor (conv3x3_mfma.h, UPF) -- no upsample launch, no `up` tensor.  UNETPP_NO_UPF=1 keeps the
+    // separate kernel (A/B measurements).
+    const bool upf = l == 0 && !getenv("UNETPP_NO_UPF");
+    if (!upf) up[l] = b.tensor(std::string(tn) + "u", NB[l + 1], l);
     da[l] = b.tensor(std::string(tn) + "a", NB[l], l);
     d[l] = b.tensor(tn, NB[l], l);
-    b.up(l == 3 ? x[4] : d[l + 1], up[l]);
+    if (!upf) b.up(low, up[l]);
     snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
-    b.conv(std::string(nm) + ".conv1", NB[l] + NB[l + 1], x[l], up[l], da[l]);     // cat([skip, up]) (unetpp.py:112-116)
+    const int ci = b.conv(std::string(nm) + ".conv1", NB[l] + NB[l + 1], x[l], upf ? low : up[l], da[l]);     // cat([skip, up]) (unetpp.py:112-116)
+    e->convs[ci].upf = upf;
     b.conv(std::string(nm) + ".conv2", NB[l], da[l], -1, d[l]);
     if (l == 0) e->ops.back().fuse_head = true;
   }
@@ -742,7 +754,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
         double px = (double)nb * H * W;
         double flops = 2.0 * px * L.cout * L.cin_real * 9;
-        double bytes = px * P * 2.0 * (t0.C + c1 + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+        double bytes = px * P * 2.0 * (t0.C + (L.upf ? c1 / 4.0 : c1) + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
         if (head) {
           a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
           a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tpe;
@@ -753,7 +765,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           head_done = true;
         }
         char lbl[128];
-        snprintf(lbl, sizeof lbl, "%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s>", L.name.c_str(), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false");
+        snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s%s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? ", true" : "");
         Lx.run(lbl, flops, bytes, [&] { return launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s); });
       } else if (op.kind == OP_UP) {
         const Tensor& low = e->tensors[op.idx];
