@@ -70,6 +70,9 @@ struct ConvArgs {
   int rule;              // UNETPP_RULE_*
   float t_cable, t_tape, bg_margin, ct_margin;
   unsigned* status;      // engine's sticky range flags (ST_*), see range_flag
+#ifdef UNETPP_WS_DBG
+  int dbg;               // measurement builds only: phases of conv3x3_ws_kernel switched off (results are garbage)
+#endif
 };
 
 // ---- range status -------------------------------------------------------------------------------------
@@ -185,6 +188,19 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // fp16 (hi/lo planes when P == 2), exchanges words with lane ^ 32 (v_permlane32_swap) so that every lane
 // owns 8 consecutive channels, and stores 16 bytes per plane and channel block.
 // dst -> plane 0 of the pixel in the tile's first channel block; blk_stride = halves between channel blocks.
+// (hi, lo) fp16 planes of two fp32 values, packed: hi = RNE(v), lo = RNE(v - hi).  v - hi is exact in fp32, so the
+// mixed-precision FMA (fp16 operand read straight out of the packed word) gives the same bits as cvt + sub with
+// 4 instead of 10 instructions per pair.  The caller guarantees |v| <= 65504 (see range_flag).
+__device__ __forceinline__ void split_pack2(float v0, float v1, unsigned& wh, unsigned& wl) {
+  half2v ph = {(half_t)v0, (half_t)v1};                 // v_cvt_pk_f16_f32
+  wh = __builtin_bit_cast(unsigned, ph);
+  float l0, l1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(wh), "v"(v0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(wh), "v"(v1));
+  half2v pl = {(half_t)l0, (half_t)l1};
+  wl = __builtin_bit_cast(unsigned, pl);
+}
+
 template <int P>
 __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
   unsigned wh[4][2], wl[4][2];
@@ -192,15 +208,12 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
-      // clamp to the fp16 range (both signs: the transposed conv has no ReLU); the caller has reported it (range_flag)
-      const float v0 = __builtin_amdgcn_fmed3f(v[4 * q + 2 * w2], -F16_MAX, F16_MAX);
-      const float v1 = __builtin_amdgcn_fmed3f(v[4 * q + 2 * w2 + 1], -F16_MAX, F16_MAX);
-      const half_t h0 = (half_t)v0, h1 = (half_t)v1;
-      half2v ph = {h0, h1};
-      wh[q][w2] = __builtin_bit_cast(unsigned, ph);
+      const float v0 = v[4 * q + 2 * w2], v1 = v[4 * q + 2 * w2 + 1];      // within the fp16 range: the caller clamped
       if (P == 2) {
-        half2v pl = {(half_t)(v0 - (float)h0), (half_t)(v1 - (float)h1)};
-        wl[q][w2] = __builtin_bit_cast(unsigned, pl);
+        split_pack2(v0, v1, wh[q][w2], wl[q][w2]);
+      } else {
+        half2v ph = {(half_t)v0, (half_t)v1};
+        wh[q][w2] = __builtin_bit_cast(unsigned, ph);
       }
     }
 #pragma unroll
@@ -611,7 +624,13 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
         }
         // fp16 planes end at 65504: the store below clamps, and says so in the engine's sticky status word.  (A NaN
         // cannot arise here: inputs are sanitised by convert_input, weights are checked when they are loaded.)
-        if (!HEAD && __builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
+        if (!HEAD && __builtin_amdgcn_ballot_w64(vmax > F16_MAX)) {      // rare: report, then clamp to what fp16 can hold
+          range_flag(a.status, vmax > F16_MAX, false);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int m = 0; m < MW; ++m) v[m][r] = fminf(v[m][r], F16_MAX);
+        }
         if (!HEAD) {
 #pragma unroll
           for (int m = 0; m < MW; ++m) {

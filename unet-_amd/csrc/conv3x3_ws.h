@@ -1,0 +1,541 @@
+// conv3x3_ws.h — the 3x3 convolution of conv3x3_mfma.h for the narrow full-resolution layers (Cout = 32: conv0_0.*,
+// conv0_4.*, reference src/models/unetpp.py:68,82,104,116), with the work of a workgroup SPLIT BY ROLE:
+//
+//   waves 0-3  consumers   fragment reads + MFMAs (one wave per SIMD, 4 rows x 32 pixels x 32 channels each), epilogue
+//   waves 4-7  producers   everything that fills LDS: halo / weight-slab LDS-DMA, and (UPF) the bilinear x2 upsample
+//                          of the `up` channels, interpolated into the halo image from low-res pixel records
+//
+// Why: with all eight waves running the same program (conv3x3_mfma.h) they move in lock-step, one workgroup per CU
+// (LDS), so load issue, interpolation, matrix work and epilogue of a tile ADD UP — the Cout = 32 layers ran with the
+// matrix pipe 38-52 % busy and the fused upsample's VALU work did not hide at all.  A consumer and a
+// producer wave share each SIMD; the matrix pipe and the VALU/LDS/VMEM paths are separate, so the producer's
+// instructions issue in the 24 of every 32 cycles an MFMA leaves free.  Producers run one K-chunk ahead: while the
+// consumers multiply chunk g out of stage buffer g & 1, the producers fill buffer (g + 1) & 1; one s_barrier per
+// chunk hands a buffer over in each direction.
+//
+// Tile = 16 rows x 32 pixels x 32 output channels, K = 9 taps x (C0 [+ C1]) in chunks of 16 channels; activations
+// channel-blocked [N][C/16][H][W][P][16] (conv3x3_mfma.h); same LDS images, same packed weights.
+// Consumers walk a chunk dx-major: the six halo rows a wave needs for one column shift are read once (12 ds_read_b128)
+// and serve the three taps of that column (36 MFMAs): half the fragment reads of the tap-major order.
+//
+// UPF (fused bilinear upsample, unetpp.py:76,112-116: cat([skip, up(low)])): `in1` is the LOW-resolution tensor
+// [N][C1/16][H/2][W/2][P][16].  Per tile and up-chunk the <= 10 x 18 low-res pixel records it needs arrive by LDS-DMA one
+// producer iteration ahead.  With tile origins at multiples of (16, 32) every 2x2 block of halo pixels starting at an
+// odd image row / column reads the SAME four low-res pixels (align_corners=True, src = dst * (in-1)/(out-1): checked
+// for all sizes up to 4096 in tests/test_host_logic.py), so one producer lane takes a block x 4 channels: 8 ds_read_b64,
+// the four corner values c = hi + lo (exact in fp32), two x-interpolations per row, four y-interpolations, the
+// hi/lo re-split, 8 ds_write_b64.
+#pragma once
+#include "conv3x3_mfma.h"
+
+namespace unetpp {
+
+template <int P, bool UPF>
+struct WsCfg {
+  static constexpr int NT = 512, NCONS = 4, NPROD = 4, MW = 4;
+  static constexpr int TH = NCONS * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
+  static constexpr int KC = 16, KG = 2, BN = 32;
+  static constexpr int U = P * KG, PPP = 64 / U;
+  static constexpr int HALO_PIECES = (NHALO + PPP - 1) / PPP, HALO_BYTES = HALO_PIECES * 1024;
+  static constexpr int HALO_ITERS = (HALO_PIECES + NPROD - 1) / NPROD;
+  static constexpr int SLAB_BYTES = P * 9 * KC * BN * 2, SLAB_PIECES = SLAB_BYTES / 1024;
+  static constexpr int SLAB_ITERS = (SLAB_PIECES + NPROD - 1) / NPROD;
+  static constexpr int BUF_BYTES = HALO_BYTES + SLAB_BYTES;
+  static constexpr int LSH = TH / 2 + 2, LSW = TW / 2 + 2, LS_PX = LSH * LSW, LS_REC = P * 32;
+  static constexpr int LS_PIECES = (LS_PX * LS_REC + 1023) / 1024, LS_BYTES = UPF ? LS_PIECES * 1024 : 0;
+  static constexpr int LS_ITERS = (LS_PIECES + NPROD - 1) / NPROD;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 2 * LS_BYTES;
+  // interpolation items: 2x2 halo blocks x channel quads
+  static constexpr int BLK_Y = (TH + 2) / 2, BLK_X = HALO_W / 2, UP_ITEMS = BLK_Y * BLK_X * 4;
+  static constexpr int UP_ROUNDS = (UP_ITEMS + NPROD * 64 - 1) / (NPROD * 64);
+  static_assert(SLAB_BYTES % 1024 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's global
+// stores (vmcnt), so a consumer's epilogue stores keep draining while it already multiplies the next tile.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Epilogue of ROWS image rows (acc[m] = row gy0 + m) x 32 pixels x 32 channels [cbase, cbase + 32) held in MFMA
+// accumulators (pixel on the lane, channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) in register r): scale, bias, ReLU,
+// then either the fp16 hi/lo store (+ the fused 2x2 max-pool of rows (0,1), (2,3), ...) or the fused 1x1 head with
+// softmax / argmax / class rules.  Same arithmetic, statement for statement, as the epilogue of conv3x3_bias_relu_kernel.
+template <int P, int ROWS, bool POOL, bool HEAD>
+__device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&acc)[ROWS], const float2* sb_lds,
+                                            const float* head_lds, int n, int gy0, int x0, int cbase, int lane) {
+  const int H = a.H, W = a.W;
+  const int h = lane >> 5;
+  const int gx = x0 + (lane & 31);
+  const int nbo = a.Cout >> 4;
+  float v[ROWS][16];
+  float vmax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float2 sb = sb_lds[co];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      v[m][r] = fmaxf(acc[m][r] * sb.x + sb.y, 0.f);
+      if (!HEAD) vmax = fmaxf(vmax, v[m][r]);           // x0_4 stays in fp32 registers in the fused head: nothing to clamp
+    }
+  }
+  if (!HEAD && __builtin_amdgcn_ballot_w64(vmax > F16_MAX)) {      // rare: report, then clamp to what fp16 can hold
+    range_flag(a.status, vmax > F16_MAX, false);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m) v[m][r] = fminf(v[m][r], F16_MAX);
+  }
+  if (!HEAD) {
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      const int gy = gy0 + m;
+      const bool ok = gy < H && gx < W;
+      const size_t blk = (size_t)H * W * P * 16;
+      half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)gy * W + gx) * P * 16;
+      pack_store_octets<P>(v[m], dst, blk, ok, h);
+    }
+  } else {
+    // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: a lane holds 16 of a pixel's 32 channels, lane ^ 32 the
+    // other 16.  Rows are finished in pairs: one v_permlane32_swap hands the low half-wave both partial sums of row 2i
+    // and the high half-wave both of row 2i+1, so each half-wave finishes (argmax, softmax, rules, stores) a different
+    // row instead of both doing both.  Sum order (lanes 0-31's part first) as in conv3x3_bias_relu_kernel: same bits.
+    static_assert(!HEAD || ROWS % 2 == 0, "fused head: row pairs");
+    const size_t hw = (size_t)H * W;
+#pragma unroll
+    for (int m2 = 0; m2 < ROWS / 2; ++m2) {
+      float lg[HEAD_FUSED_MAX_CLASSES];
+#pragma unroll
+      for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+        lg[c] = -INFINITY;
+        if (c < a.head_C) {       // uniform branch
+          float wq[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 w4 = *(const float4*)(head_lds + c * 32 + 8 * q + 4 * h);
+            wq[4 * q] = w4.x; wq[4 * q + 1] = w4.y; wq[4 * q + 2] = w4.z; wq[4 * q + 3] = w4.w;
+          }
+          const float bc = head_lds[a.head_C * 32 + c];
+          float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { p0 = fmaf(v[2 * m2][r], wq[r], p0); p1 = fmaf(v[2 * m2 + 1][r], wq[r], p1); }
+          auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), false, false);
+          unsigned s0 = sw[0], s1 = sw[1];
+          // hipcc (ROCm 7.2) pads nothing between v_permlane32_swap and a VALU instruction reading its results, and the
+          // add then sees stale registers (measured: sum = 2 * s0); stores of swapped words are not affected
+          asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));
+          lg[c] = bc + (__builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1));
+        }
+      }
+      const int gy = gy0 + 2 * m2 + h;                 // this half-wave's row
+      const bool ok = gy < H && gx < W;
+      const size_t pix = (size_t)gy * W + gx;
+      float best = lg[0];
+      int besti = 0;
+#pragma unroll
+      for (int c = 1; c < HEAD_FUSED_MAX_CLASSES; ++c)
+        if (lg[c] > best) { best = lg[c]; besti = c; }        // first maximal class wins
+      bool is_cable = besti == 1, is_tape = besti == 2;
+      if (a.probs || a.rule) {      // uniform: softmax_np = exp(x - max) / sum, fp32
+        float pe[HEAD_FUSED_MAX_CLASSES], sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+          pe[c] = (c < a.head_C) ? expf(lg[c] - best) : 0.f;
+          sum += pe[c];
+        }
+#pragma unroll
+        for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) {
+          pe[c] = pe[c] / sum;
+          if (ok && a.probs && c < a.head_C) a.probs[((size_t)n * a.head_C + c) * hw + pix] = pe[c];
+        }
+        if (a.rule) apply_rule(a.rule, pe[0], pe[1], pe[2], a.t_cable, a.t_tape, a.bg_margin, a.ct_margin, is_cable, is_tape);
+      }
+      if (ok) {
+        if (a.logits) {
+#pragma unroll
+          for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c)
+            if (c < a.head_C) a.logits[((size_t)n * a.head_C + c) * hw + pix] = lg[c];
+        }
+        const size_t o = (size_t)n * hw + pix;
+        if (a.mask) a.mask[o] = (uint8_t)besti;
+        if (a.cable) a.cable[o] = is_cable;
+        if (a.tape) a.tape[o] = is_tape;
+      }
+    }
+  }
+  if (POOL) {
+    static_assert(!POOL || ROWS % 2 == 0, "fused pool: row pairs");
+    const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+    for (int m2 = 0; m2 < ROWS / 2; ++m2) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float vm = fmaxf(v[2 * m2][r], v[2 * m2 + 1][r]);
+        const float vn = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, vm), 0xB1, 0xF, 0xF, true));
+        pv[r] = fmaxf(vm, vn);       // quad_perm [1,0,3,2]: the horizontally adjacent pixel
+      }
+      const int py = (gy0 >> 1) + m2, px = (x0 >> 1) + ((lane & 31) >> 1);
+      const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
+      const size_t blk = (size_t)Hp * Wp * P * 16;
+      half_t* dst = a.pool_out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)py * Wp + px) * P * 16;
+      pack_store_octets<P>(pv, dst, blk, ok, h);
+    }
+  }
+}
+
+template <int P, bool POOL, bool HEAD, bool UPF>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
+  using C = WsCfg<P, UPF>;
+  constexpr int NT = C::NT, MW = C::MW, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
+  constexpr int KC = C::KC, KG = C::KG, BN = C::BN, PPP = C::PPP;
+  static_assert(!(POOL && HEAD) && !(UPF && (POOL || HEAD)), "one fused extra per kernel");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W;
+  const int tiles_img = a.tiles_x * a.tiles_y;
+  const int total_tiles = a.N * tiles_img;              // Cout == 32: one channel tile
+  const int nch0 = (a.C0 + KC - 1) / KC;
+  const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
+
+  // per-channel (scale, bias) of the layer and the head weights, staged once per workgroup (read by the consumers)
+  float2* sb_lds = (float2*)(smem + C::LDS_BYTES);
+  for (int i = tid; i < a.Cout; i += NT) sb_lds[i] = make_float2(a.scale[i], a.bias[i]);
+  float* head_lds = (float*)(smem + C::LDS_BYTES + a.Cout * 8);
+  if (HEAD) {
+    for (int i = tid; i < a.head_C * 32; i += NT) head_lds[i] = a.head_w[i];
+    for (int i = tid; i < a.head_C; i += NT) head_lds[a.head_C * 32 + i] = a.head_b[i];
+  }
+
+  // tile order as in conv3x3_bias_relu_kernel: an XCD (workgroups b, b+8, ...) walks a contiguous run of tiles
+  const int G = (int)gridDim.x;
+  const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  auto decode = [&](int t, int& n, int& y0, int& x0) {
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    n = t / a.tiles_y;
+    x0 = tx * TW; y0 = ty * TH;
+  };
+  if (slot >= total_tiles) return;                       // whole workgroup: no barrier has been executed yet
+  __syncthreads();                                       // sb_lds / head_lds visible
+
+  if (wave >= C::NCONS) {
+    // =============================================================== producers
+    const int pw = wave - C::NCONS;
+    constexpr unsigned OOB = 0x80000000u;                // beyond num_records: the buffer load returns zeros
+    constexpr int ITERS = C::HALO_ITERS;
+    // tile-invariant: halo pixel / unit of this lane in each of its DMA pieces (as in conv3x3_bias_relu_kernel)
+    const int my_u = lane / PPP;
+    const int my_pl = my_u / KG, my_k8 = (my_u % KG) * 8;
+    int hyx[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int hp = (pw + it * C::NPROD) * PPP + lane % PPP;
+      const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+      hyx[it] = (hp < C::NHALO) ? ((hy << 8) | hx) : -1;
+    }
+    const int cb0 = a.C0 < 16 ? a.C0 : 16;
+    const unsigned plane_bytes0 = (unsigned)(H * W * P * cb0 * 2);
+    const unsigned img_bytes0 = (unsigned)(H * W * P * a.C0 * 2);
+    const int Hs = H >> 1, Ws = W >> 1;
+    const unsigned plane_bytes1 = (unsigned)(Hs * Ws * P * 16 * 2);
+    const unsigned img_bytes1 = (unsigned)(Hs * Ws * P * a.C1 * 2);
+    const float up_sh = Hs > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
+    const float up_sw = Ws > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f;
+
+    unsigned voff0[ITERS];
+    __amdgpu_buffer_rsrc_t rsrc0, rsrc1;
+    constexpr int LSR = UPF ? C::LS_ITERS : 1, UPR = UPF ? C::UP_ROUNDS : 1;
+    unsigned voffL[LSR];
+    // interpolation item r of this lane: block (by, bx) x channel quad q
+    int up_o00[UPR], up_o01[UPR], up_o10[UPR];          // staging offsets of the corners (ra,ca), (ra,cb), (rb,ca)
+    float up_wx[UPR][4], up_wy[UPR][4];                  // {lx0, lx1} of the block's two columns, {ly0, ly1} of its two rows
+    int up_dst[UPR];                                     // halo-image offset of the block's first pixel, -1 = no item
+    if (UPF) {
+#pragma unroll
+      for (int r = 0; r < UPR; ++r) {
+        const int i = pw * 64 + lane + r * (C::NPROD * 64);
+        const int q = i & 3, blk = i >> 2;
+        const int by = blk / C::BLK_X, bx = blk - by * C::BLK_X;
+        const int hp = (2 * by) * HALO_W + 2 * bx;
+        // first pixel of the block; its right neighbour is hp + 1, the row below hp + HALO_W (computed at the store)
+        up_dst[r] = i < C::UP_ITEMS ? hp * 4 + q : -1;
+      }
+    }
+    auto halo_dst = [&](int hp, int q) {                 // byte offset of channel quad q of halo pixel hp, plane 0
+      return (hp / PPP) * 1024 + ((q >> 1) * PPP + hp % PPP) * 16 + (q & 1) * 8;
+    };
+
+    auto setup_tile = [&](int n, int y0, int x0) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const unsigned pix = (unsigned)((gy * W + gx) * P + my_pl);
+        voff0[it] = (ok && my_k8 < a.C0) ? (unsigned)(my_k8 >> 4) * plane_bytes0 + (pix * cb0 + (my_k8 & 15)) * 2u : OOB;
+      }
+      rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)n * H * W * P * a.C0), 0, (int)img_bytes0, 0x00020000);
+      if (UPF) {
+        rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 + (size_t)n * Hs * Ws * P * a.C1), 0, (int)img_bytes1, 0x00020000);
+        const int ybase = (int)(up_sh * (float)max(y0 - 1, 0)), xbase = (int)(up_sw * (float)max(x0 - 1, 0));
+        constexpr int PXP = 1024 / C::LS_REC, PARTS = C::LS_REC / 16;
+#pragma unroll
+        for (int it = 0; it < LSR; ++it) {
+          const int lp = (pw + it * C::NPROD) * PXP + lane / PARTS;
+          const int ly = lp / C::LSW, lx = lp - ly * C::LSW;
+          const int yy = min(ybase + ly, Hs - 1), xx = min(xbase + lx, Ws - 1);
+          voffL[it] = lp < C::LS_PX ? (unsigned)((yy * Ws + xx) * C::LS_REC + (lane % PARTS) * 16) : OOB;
+        }
+#pragma unroll
+        for (int r = 0; r < UPR; ++r) {
+          const int i = pw * 64 + lane + r * (C::NPROD * 64);
+          const int q = i & 3, blk = i >> 2;
+          const int by = blk / C::BLK_X, bx = blk - by * C::BLK_X;
+          // the block's two image rows / columns: the first is odd (or -1), the second even; those inside the image
+          // share their low-res corner pair (see the header), taken from the second unless only the first is inside
+          const int gyA = y0 + 2 * by - 1, gxA = x0 + 2 * bx - 1;
+          const int gyR = (gyA + 1 < H) ? gyA + 1 : gyA, gxR = (gxA + 1 < W) ? gxA + 1 : gxA;
+          const float fyR = up_sh * (float)max(gyR, 0), fxR = up_sw * (float)max(gxR, 0);
+          const int yy0 = min((int)fyR, Hs - 1), xx0 = min((int)fxR, Ws - 1);
+          const int yy1 = yy0 + (yy0 < Hs - 1 ? 1 : 0), xx1 = xx0 + (xx0 < Ws - 1 ? 1 : 0);
+          const int ry0 = min(max(yy0 - ybase, 0), C::LSH - 1), ry1 = min(max(yy1 - ybase, 0), C::LSH - 1);
+          const int rx0 = min(max(xx0 - xbase, 0), C::LSW - 1), rx1 = min(max(xx1 - xbase, 0), C::LSW - 1);
+          up_o00[r] = (ry0 * C::LSW + rx0) * C::LS_REC + q * 8;
+          up_o01[r] = (ry0 * C::LSW + rx1) * C::LS_REC + q * 8;
+          up_o10[r] = (ry1 * C::LSW + rx0) * C::LS_REC + q * 8;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int gy = gyA + k, gx = gxA + k;
+            const bool iny = gy >= 0 && gy < H, inx = gx >= 0 && gx < W;
+            const float ly1 = fminf(fmaxf(up_sh * (float)max(gy, 0) - (float)yy0, 0.f), 1.f);
+            const float lx1 = fminf(fmaxf(up_sw * (float)max(gx, 0) - (float)xx0, 0.f), 1.f);
+            up_wy[r][2 * k] = iny ? 1.f - ly1 : 0.f; up_wy[r][2 * k + 1] = iny ? ly1 : 0.f;   // zero padding: all weights 0
+            up_wx[r][2 * k] = inx ? 1.f - lx1 : 0.f; up_wx[r][2 * k + 1] = inx ? lx1 : 0.f;
+          }
+        }
+      }
+    };
+
+    // one interpolation item: 2x2 halo pixels x 4 channels of up-chunk c, staging buffer (c & 1) -> halo image
+    auto up_item = [&](int c, int halo_off, int r) {
+      if (up_dst[r] < 0) return;
+      typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+      const char* ls = smem + 2 * C::BUF_BYTES + (c & 1) * C::LS_BYTES;
+      const int o11 = up_o10[r] + (up_o01[r] - up_o00[r]);
+      half4 h00, h01, h10, h11, l00, l01, l10, l11;
+#ifdef UNETPP_WS_DBG
+      if (a.dbg & 64) {
+        for (int e = 0; e < 4; ++e) { h00[e] = h01[e] = h10[e] = h11[e] = (half_t)up_wx[r][0]; l00[e] = l01[e] = l10[e] = l11[e] = (half_t)up_wy[r][1]; }
+      } else
+#endif
+      {
+      h00 = *(const half4*)(ls + up_o00[r]); h01 = *(const half4*)(ls + up_o01[r]);
+      h10 = *(const half4*)(ls + up_o10[r]); h11 = *(const half4*)(ls + o11);
+      if (P == 2) {
+        l00 = *(const half4*)(ls + up_o00[r] + 32); l01 = *(const half4*)(ls + up_o01[r] + 32);
+        l10 = *(const half4*)(ls + up_o10[r] + 32); l11 = *(const half4*)(ls + o11 + 32);
+      }
+      }
+      half4 oh[4], ol[4];                                // pixel (ky, kx) -> index 2 * ky + kx
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float c00 = (float)h00[e], c01 = (float)h01[e], c10 = (float)h10[e], c11 = (float)h11[e];
+        if (P == 2) { c00 += (float)l00[e]; c01 += (float)l01[e]; c10 += (float)l10[e]; c11 += (float)l11[e]; }   // exact
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) {
+          const float t0 = fmaf(up_wx[r][2 * kx + 1], c01, up_wx[r][2 * kx] * c00);     // x inside each row first
+          const float t1 = fmaf(up_wx[r][2 * kx + 1], c11, up_wx[r][2 * kx] * c10);
+#pragma unroll
+          for (int ky = 0; ky < 2; ++ky) {
+            const float v = fmaf(up_wy[r][2 * ky + 1], t1, up_wy[r][2 * ky] * t0);
+            const half_t hi = (half_t)v;
+            oh[2 * ky + kx][e] = hi;
+            if (P == 2) ol[2 * ky + kx][e] = (half_t)(v - (float)hi);
+          }
+        }
+      }
+      const int hp0 = up_dst[r] >> 2, q = up_dst[r] & 3;
+#ifdef UNETPP_WS_DBG
+      if ((a.dbg & 32) && !(oh[0][0] == (half_t)12345.f && ol[3][1] == (half_t)7.f)) return;
+#endif
+#pragma unroll
+      for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) {
+          char* dst = smem + halo_off + halo_dst(hp0 + ky * HALO_W + kx, q);
+          *(half4*)dst = oh[2 * ky + kx];
+          if (P == 2) *(half4*)(dst + KG * PPP * 16) = ol[2 * ky + kx];
+        }
+    };
+
+    int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
+    for (int tile = slot; tile < total_tiles; tile += G) {
+      int n, y0, x0;
+      decode(tile, n, y0, x0);
+      setup_tile(n, y0, x0);
+      const char* wsrc = (const char*)a.wpk;
+      for (int c = 0; c < a.nchunks; ++c, ++g) {
+        const int buf = (g & 1) * C::BUF_BYTES;
+#ifdef UNETPP_WS_DBG
+        if (!(a.dbg & 2))
+#endif
+        if (c < nch0) {
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            const int piece = pw + it * C::NPROD;
+            if (C::HALO_PIECES % C::NPROD == 0 || piece < C::HALO_PIECES)
+              blds16(rsrc0, voff0[it], c * (int)plane_bytes0, lds_base + buf + piece * 1024);
+          }
+        }
+#ifdef UNETPP_WS_DBG
+        if (!(a.dbg & 8))
+#endif
+#pragma unroll
+        for (int it = 0; it < C::SLAB_ITERS; ++it) {
+          const int piece = pw + it * C::NPROD;
+          if (C::SLAB_PIECES % C::NPROD == 0 || piece < C::SLAB_PIECES)
+            glds16(wsrc + (size_t)c * C::SLAB_BYTES + piece * 1024, lane * 16, lds_base + buf + C::HALO_BYTES + piece * 1024);
+        }
+        if (UPF) {
+#ifdef UNETPP_WS_DBG
+          if (!(a.dbg & 2))
+#endif
+          if (c + 1 < a.nchunks && c + 1 >= nch0) {      // low-res records of the NEXT chunk, one iteration ahead
+#pragma unroll
+            for (int it = 0; it < LSR; ++it) {
+              const int piece = pw + it * C::NPROD;
+              if (C::LS_PIECES % C::NPROD == 0 || piece < C::LS_PIECES)
+                blds16(rsrc1, voffL[it], (c + 1 - nch0) * (int)plane_bytes1,
+                       lds_base + 2 * C::BUF_BYTES + ((c + 1) & 1) * C::LS_BYTES + piece * 1024);
+            }
+          }
+#ifdef UNETPP_WS_DBG
+          if (!(a.dbg & 1))
+#endif
+          if (c >= nch0) {                                // this chunk's halo image from the records that landed last iteration
+#pragma unroll
+            for (int r = 0; r < UPR; ++r) up_item(c, buf, r);
+          }
+        }
+#ifdef UNETPP_WS_DBG
+        if (!(a.dbg & 128))
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        lds_barrier();                                    // chunk g published; the consumers have left buffer (g+1) & 1
+      }
+    }
+    return;
+  }
+
+  // ================================================================= consumers
+  const int cw = wave;
+  // lane-constant LDS read offsets: pixel fragment of halo row r (0 .. MW+1 of this wave) shifted by dx
+  int a_off[MW + 2][3];
+#pragma unroll
+  for (int r = 0; r < MW + 2; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hp = (cw * MW + r) * HALO_W + (lane & 31) + dx;
+      a_off[r][dx] = (hp / PPP) * 1024 + ((lane >> 5) * PPP + hp % PPP) * 16;
+    }
+  const int b_lane_off = ((lane >> 5) * BN + (lane & 31)) * 16;
+  struct AFrag { half8 h[MW + 2], l[MW + 2]; };
+  struct BFrag { half8 h, l; };
+  auto load_a = [&](AFrag& f, const char* halo, int dx) {
+#pragma unroll
+    for (int r = 0; r < MW + 2; ++r) {
+      const char* p = halo + a_off[r][dx];
+      f.h[r] = *(const half8*)p;
+      if (P == 2) f.l[r] = *(const half8*)(p + KG * PPP * 16);
+    }
+  };
+  auto load_a_part = [&](AFrag& f, const char* halo, int dx, int r0, int r1) {
+#pragma unroll
+    for (int r = 0; r < MW + 2; ++r)
+      if (r >= r0 && r < r1) {
+        const char* p = halo + a_off[r][dx];
+        f.h[r] = *(const half8*)p;
+        if (P == 2) f.l[r] = *(const half8*)(p + KG * PPP * 16);
+      }
+  };
+  auto load_b = [&](BFrag& f, const char* slab, int tap) {
+    const int off = b_lane_off + tap * KG * BN * 16;
+    f.h = *(const half8*)(slab + off);
+    if (P == 2) f.l = *(const half8*)(slab + off + 9 * KC * BN * 2);
+  };
+  float16v acc[MW];
+  auto run_mfma = [&](const AFrag& fa, const BFrag& fb, int dy) {
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      if (P == 2) {
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h, fa.l[m + dy], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.l, fa.h[m + dy], acc[m], 0, 0, 0);
+      }
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h, fa.h[m + dy], acc[m], 0, 0, 0);
+    }
+  };
+
+  int g = 0;
+  for (int tile = slot; tile < total_tiles; tile += G) {
+    int n, y0, x0;
+    decode(tile, n, y0, x0);
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int c = 0; c < a.nchunks; ++c, ++g) {
+      lds_barrier();                                      // chunk g is in stage buffer g & 1
+      const char* halo = smem + (g & 1) * C::BUF_BYTES;
+      const char* slab = halo + C::HALO_BYTES;
+      // dx-major walk: the six halo rows of one column shift serve its three taps.  Fragments of the next tap
+      // (and, spread over the three taps, the next column shift) are read before this tap's MFMAs.
+#ifdef UNETPP_WS_DBG
+      if (a.dbg & 16) continue;
+#endif
+      AFrag fa0, fa1;
+      BFrag fb0, fb1;
+      load_a(fa0, halo, 0);
+      load_b(fb0, slab, 0);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        AFrag& fa = (dx & 1) ? fa1 : fa0;
+        AFrag& fan = (dx & 1) ? fa0 : fa1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int step = dx * 3 + dy;
+          BFrag& fb = (step & 1) ? fb1 : fb0;
+          BFrag& fbn = (step & 1) ? fb0 : fb1;
+          if (step + 1 < 9) {
+            const int ndx = (step + 1) / 3, ndy = (step + 1) % 3;
+            load_b(fbn, slab, ndy * 3 + ndx);
+          }
+          if (dx < 2) load_a_part(fan, halo, dx + 1, 2 * dy, 2 * dy + 2);
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef UNETPP_WS_DBG
+          if (!(a.dbg & 4))
+#endif
+          run_mfma(fa, fb, dy);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- epilogue from registers, two row pairs; the producers are already filling the next tile's first chunk
+#ifdef UNETPP_WS_DBG
+    if (a.dbg & 256) { if (acc[0][0] == 12345.f && acc[3][5] == 7.f) a.status[1] = 1; continue; }
+#endif
+#pragma unroll
+    for (int m2 = 0; m2 < MW / 2; ++m2) {
+      const float16v pair[2] = {acc[2 * m2], acc[2 * m2 + 1]};
+      ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, 0, lane);
+    }
+  }
+}
+
+}  // namespace unetpp

@@ -130,7 +130,11 @@ __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
       for (int r = 0; r < 16; ++r) v[r] = acc[pt][j][r] * sc[r] + bi[r];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) vmax = fmaxf(fmaxf(vmax, fabsf(v[r])), fabsf(v[r + 1]));
-      if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
+      if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) {            // rare: report, then clamp to what fp16 can hold
+        range_flag(a.status, vmax > F16_MAX, false);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], -F16_MAX, F16_MAX);
+      }
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * oblk + ((size_t)(2 * y + dy) * W2 + (2 * x + dx)) * (P * 16);
       pack_store_octets<P>(v, dst, oblk, ok, h);
     }

@@ -30,6 +30,7 @@
 #include "../../include/unetpp.h"
 #include "aux_kernels.h"
 #include "conv3x3_mfma.h"
+#include "conv3x3_ws.h"
 #include "convt2x2_mfma.h"
 
 using namespace unetpp;
@@ -130,6 +131,7 @@ struct unetpp_engine {
   hipEvent_t ev_start = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
   // frame glue: per-axis resize tables on the device, keyed by (kind, n_src, n_dst); kind 0 = linear, 1 = nearest
   std::map<std::tuple<int, int, int>, void*> resize_tabs;
+  bool use_ws = true;             // wave-specialised kernel for the Cout = 32 layers (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
 };
 
@@ -232,6 +234,29 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
+}
+
+// wave-specialised kernel for the Cout = 32 layers (conv3x3_ws.h): 16-row tiles, one persistent workgroup per CU
+template <int P, bool POOL, bool HEAD, bool UPF>
+hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
+  using C = WsCfg<P, UPF>;
+  a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = 1;
+  const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
+  const int total = a.N * a.tiles_x * a.tiles_y;
+  dim3 grid((unsigned)std::min(total, cx.num_cus));
+  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF>;
+  hipError_t st = allow_full_lds((const void*)k, cx.device);
+  if (st != hipSuccess) return st;
+  hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, hipStream_t s) {
+  if (P != 2 || a.Cout != 32 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
+  if (upf) return launch_ws_k<2, false, false, true>(cx, a, s);
+  if (head) return launch_ws_k<2, false, true, false>(cx, a, s);
+  if (pool) return launch_ws_k<2, true, false, false>(cx, a, s);
+  return launch_ws_k<2, false, false, false>(cx, a, s);
 }
 
 template <int P, int KC, int NW, int MW, int WAVES>
@@ -505,6 +530,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
   }
   e->cfg = *cfg;
+  e->use_ws = !getenv("UNETPP_NO_WS");
   e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
   e->nstreams = std::max(1, std::min(4, cfg->streams));
@@ -748,6 +774,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
         a.status = e->d_status;
+#ifdef UNETPP_WS_DBG
+        { const char* d = getenv("UNETPP_WS_DBG"); a.dbg = d ? atoi(d) : 0; }
+#endif
         const int mw = small_grid_rows(L, e->num_cus, nb, H, W, head);
         const int TH = L.WAVES * mw;
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
@@ -764,9 +793,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           bytes += px * ((lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tpe ? 1 : 0));
           head_done = true;
         }
-        char lbl[128];
-        snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s%s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? ", true" : "");
-        Lx.run(lbl, flops, bytes, [&] { return launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s); });
+        // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
+        const bool ws = e->use_ws && P == 2 && L.cout == 32 && (L.in2 < 0 || L.upf);
+        char lbl[160];
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? "true" : "false");
+        else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s%s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? ", true" : "");
+        Lx.run(lbl, flops, bytes, [&] {
+          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, s)
+                    : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
+        });
       } else if (op.kind == OP_UP) {
         const Tensor& low = e->tensors[op.idx];
         const Tensor& dst = e->tensors[op.out];
