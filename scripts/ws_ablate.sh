@@ -1,0 +1,15 @@
+#!/bin/bash
+# Phase ablations of conv3x3_ws_kernel: builds the library with -DUNETPP_WS_DBG, runs the per-layer
+# profile once per UNETPP_WS_DBG value given on the command line, then rebuilds the product library.
+#   bits: 1 no interpolation, 2 no halo / low-res DMA, 4 no MFMAs, 8 no slab DMA, 16 no consumer work at all,
+#         128 no DMA wait, 256 no epilogue; bits 10-11 producer s_setprio, 12-13 consumer s_setprio.  Results are garbage.
+# usage (on the GPU box, from the repo root): scripts/ws_ablate.sh 0 1 4 256 ...
+set -e
+cd "$(dirname "$0")/.."
+H=$(python -c 'from unet_amd import _lib; print(_lib.source_hash())')
+(cd unet-_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DUNETPP_WS_DBG=1 -DUNETPP_SRC_HASH=\"$H\" -o ../libunetpp_hip.so unetpp_abi.hip)
+for d in "$@"; do
+  echo "UNETPP_WS_DBG=$d"
+  UNETPP_ALLOW_DBG_LIB=1 UNETPP_WS_DBG=$d timeout -k 10 120 python scripts/layer_profile.py exact 2>&1 | grep "conv0_0\|conv0_4" || true
+done
+UNETPP_FORCE_BUILD=1 python __graft_entry__.py > /dev/null

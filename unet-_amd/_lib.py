@@ -69,6 +69,8 @@ def built_hash(path: str = LIB_PATH):
     if i < 0:
         return None
     tag = blob[i + 13:i + 13 + 16]
+    if blob[i + 29:i + 36] == b" +wsdbg" and not os.environ.get("UNETPP_ALLOW_DBG_LIB"):
+        return "wsdbg-build"                 # a measurement build never counts as current
     return tag.decode("ascii", "replace")
 
 
@@ -143,7 +145,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     lib.unetpp_debug_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), cs]
     lib.unetpp_debug_read.restype = ctypes.c_longlong
     lib.unetpp_debug_keep_intermediates.argtypes = [vp, ci]; lib.unetpp_debug_keep_intermediates.restype = ci
-    if not lib.unetpp_version().decode().endswith("src:" + source_hash()):
+    ver = lib.unetpp_version().decode()
+    if ver.endswith(" +wsdbg") and os.environ.get("UNETPP_ALLOW_DBG_LIB"):
+        ver = ver[:-len(" +wsdbg")]            # measurement build with phase ablations (scripts/ws_ablate.sh)
+    if not ver.endswith("src:" + source_hash()):
         raise RuntimeError(f"{LIB_PATH} reports {lib.unetpp_version().decode()!r}, tree is src:{source_hash()}")
     _lib = lib
     return lib

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   if (wave >= C::NCONS) {
     // =============================================================== producers
     const int pw = wave - C::NCONS;
+#ifdef UNETPP_WS_DBG
+    { const int pr = (a.dbg >> 10) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
+#endif
     constexpr unsigned OOB = 0x80000000u;                // beyond num_records: the buffer load returns zeros
     constexpr int ITERS = C::HALO_ITERS;
     // tile-invariant: halo pixel / unit of this lane in each of its DMA pieces (as in conv3x3_bias_relu_kernel)
@@ -310,9 +313,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           up_o00[r] = (ry0 * C::LSW + rx0) * C::LS_REC + q * 8;
           up_o01[r] = (ry0 * C::LSW + rx1) * C::LS_REC + q * 8;
           up_o10[r] = (ry1 * C::LSW + rx0) * C::LS_REC + q * 8;
+          // Lanes of the second channel octet (q >= 2) take the block's two columns in the opposite order: at every
+          // ds_write_b64 the two octets of a block then hit different pixels, hence different banks (conflict-free
+          // stores into the [unit][pixel] halo image; in the same order the octets would collide 2-way).
+          const int xs = (q >> 1) & 1;
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const int gy = gyA + k, gx = gxA + k;
+            const int gy = gyA + k, gx = gxA + (k ^ xs);
             const bool iny = gy >= 0 && gy < H, inx = gx >= 0 && gx < W;
             const float ly1 = fminf(fmaxf(up_sh * (float)max(gy, 0) - (float)yy0, 0.f), 1.f);
             const float lx1 = fminf(fmaxf(up_sw * (float)max(gx, 0) - (float)xx0, 0.f), 1.f);
@@ -323,56 +330,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
     };
 
-    // one interpolation item: 2x2 halo pixels x 4 channels of up-chunk c, staging buffer (c & 1) -> halo image
-    auto up_item = [&](int c, int halo_off, int r) {
-      if (up_dst[r] < 0) return;
-      typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+    // all interpolation items of this lane for up-chunk c: staging buffer (c & 1) -> halo image.  Straight-line code
+    // for all rounds (the LDS reads of every round are issued before the first value is needed; a lane without an
+    // item in the last round computes on clamped addresses and skips only the stores).
+    auto up_rounds = [&](int c, int halo_off) {
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       const char* ls = smem + 2 * C::BUF_BYTES + (c & 1) * C::LS_BYTES;
-      const int o11 = up_o10[r] + (up_o01[r] - up_o00[r]);
-      half4 h00, h01, h10, h11, l00, l01, l10, l11;
-#ifdef UNETPP_WS_DBG
-      if (a.dbg & 64) {
-        for (int e = 0; e < 4; ++e) { h00[e] = h01[e] = h10[e] = h11[e] = (half_t)up_wx[r][0]; l00[e] = l01[e] = l10[e] = l11[e] = (half_t)up_wy[r][1]; }
-      } else
-#endif
-      {
-      h00 = *(const half4*)(ls + up_o00[r]); h01 = *(const half4*)(ls + up_o01[r]);
-      h10 = *(const half4*)(ls + up_o10[r]); h11 = *(const half4*)(ls + o11);
-      if (P == 2) {
-        l00 = *(const half4*)(ls + up_o00[r] + 32); l01 = *(const half4*)(ls + up_o01[r] + 32);
-        l10 = *(const half4*)(ls + up_o10[r] + 32); l11 = *(const half4*)(ls + o11 + 32);
+      u32x2 hq[UPR][4], lq[UPR][4];                      // corners (ra,ca), (ra,cb), (rb,ca), (rb,cb): 4 channels each
+#pragma unroll
+      for (int r = 0; r < UPR; ++r) {
+        const int o11 = up_o10[r] + (up_o01[r] - up_o00[r]);
+        const int off[4] = {up_o00[r], up_o01[r], up_o10[r], o11};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hq[r][k] = *(const u32x2*)(ls + off[k]);
+          if (P == 2) lq[r][k] = *(const u32x2*)(ls + off[k] + 32);
+        }
       }
-      }
-      half4 oh[4], ol[4];                                // pixel (ky, kx) -> index 2 * ky + kx
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float c00 = (float)h00[e], c01 = (float)h01[e], c10 = (float)h10[e], c11 = (float)h11[e];
-        if (P == 2) { c00 += (float)l00[e]; c01 += (float)l01[e]; c10 += (float)l10[e]; c11 += (float)l11[e]; }   // exact
+      for (int r = 0; r < UPR; ++r) {
+        float v[4][4];                                   // [pixel 2 * ky + kx][channel]
 #pragma unroll
-        for (int kx = 0; kx < 2; ++kx) {
-          const float t0 = fmaf(up_wx[r][2 * kx + 1], c01, up_wx[r][2 * kx] * c00);     // x inside each row first
-          const float t1 = fmaf(up_wx[r][2 * kx + 1], c11, up_wx[r][2 * kx] * c10);
+        for (int e = 0; e < 4; ++e) {
+          float cc[4];
 #pragma unroll
-          for (int ky = 0; ky < 2; ++ky) {
-            const float v = fmaf(up_wy[r][2 * ky + 1], t1, up_wy[r][2 * ky] * t0);
-            const half_t hi = (half_t)v;
-            oh[2 * ky + kx][e] = hi;
-            if (P == 2) ol[2 * ky + kx][e] = (half_t)(v - (float)hi);
+          for (int k = 0; k < 4; ++k) {
+            // corner value = hi + lo, exact in fp32; one mixed-precision FMA reads both halves out of the packed words
+            if (P == 2) {
+              if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
+              else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
+            } else {
+              const half2v hv = __builtin_bit_cast(half2v, hq[r][k][e >> 1]);
+              cc[k] = (float)hv[e & 1];
+            }
+          }
+#pragma unroll
+          for (int kx = 0; kx < 2; ++kx) {
+            const float t0 = fmaf(up_wx[r][2 * kx + 1], cc[1], up_wx[r][2 * kx] * cc[0]);     // x inside each row first
+            const float t1 = fmaf(up_wx[r][2 * kx + 1], cc[3], up_wx[r][2 * kx] * cc[2]);
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) v[2 * ky + kx][e] = fmaf(up_wy[r][2 * ky + 1], t1, up_wy[r][2 * ky] * t0);
           }
         }
-      }
-      const int hp0 = up_dst[r] >> 2, q = up_dst[r] & 3;
-#ifdef UNETPP_WS_DBG
-      if ((a.dbg & 32) && !(oh[0][0] == (half_t)12345.f && ol[3][1] == (half_t)7.f)) return;
-#endif
+        if (up_dst[r] >= 0) {
+          const int hp0 = up_dst[r] >> 2, q = up_dst[r] & 3;
 #pragma unroll
-      for (int ky = 0; ky < 2; ++ky)
+          for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 2; ++kx) {
-          char* dst = smem + halo_off + halo_dst(hp0 + ky * HALO_W + kx, q);
-          *(half4*)dst = oh[2 * ky + kx];
-          if (P == 2) *(half4*)(dst + KG * PPP * 16) = ol[2 * ky + kx];
+            for (int kx = 0; kx < 2; ++kx) {
+              const int px = 2 * ky + kx;
+              unsigned h0, h1, l0 = 0, l1 = 0;
+              if (P == 2) {
+                split_pack2(v[px][0], v[px][1], h0, l0);
+                split_pack2(v[px][2], v[px][3], h1, l1);
+              } else {
+                half2v a0 = {(half_t)v[px][0], (half_t)v[px][1]}, a1 = {(half_t)v[px][2], (half_t)v[px][3]};
+                h0 = __builtin_bit_cast(unsigned, a0); h1 = __builtin_bit_cast(unsigned, a1);
+              }
+              const u32x2 oh = {h0, h1}, ol = {l0, l1};
+              char* dst = smem + halo_off + halo_dst(hp0 + ky * HALO_W + (kx ^ ((q >> 1) & 1)), q);
+              *(u32x2*)dst = oh;
+              if (P == 2) *(u32x2*)(dst + KG * PPP * 16) = ol;
+            }
         }
+      }
     };
 
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
@@ -419,10 +440,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
           if (!(a.dbg & 1))
 #endif
-          if (c >= nch0) {                                // this chunk's halo image from the records that landed last iteration
-#pragma unroll
-            for (int r = 0; r < UPR; ++r) up_item(c, buf, r);
-          }
+          if (c >= nch0) up_rounds(c, buf);              // this chunk's halo image from the records that landed last iteration
         }
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 128))
@@ -436,6 +454,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 
   // ================================================================= consumers
   const int cw = wave;
+#ifdef UNETPP_WS_DBG
+  { const int pr = (a.dbg >> 12) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
+#endif
   // lane-constant LDS read offsets: pixel fragment of halo row r (0 .. MW+1 of this wave) shifted by dx
   int a_off[MW + 2][3];
 #pragma unroll

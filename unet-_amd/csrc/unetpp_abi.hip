@@ -487,7 +487,12 @@ extern "C" {
 #define UNETPP_SRC_HASH "unknown"
 #endif
 // "src:<hash>" = digest of the sources this binary was built from (unet-_amd/_lib.py compares it with the tree)
-const char* unetpp_version(void) { return "unetpp-hip 0.3.0 (gfx950) src:" UNETPP_SRC_HASH; }
+#ifdef UNETPP_WS_DBG
+#define UNETPP_BUILD_TAG " +wsdbg"      /* measurement build (phase ablations): unet-_amd/_lib.py refuses it unless asked */
+#else
+#define UNETPP_BUILD_TAG ""
+#endif
+const char* unetpp_version(void) { return "unetpp-hip 0.3.0 (gfx950) src:" UNETPP_SRC_HASH UNETPP_BUILD_TAG; }
 
 const char* unetpp_last_error(const unetpp_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
