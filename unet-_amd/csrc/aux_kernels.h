@@ -68,6 +68,27 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
   *(half8*)(out + u * 8) = r;
 }
 
+// conv0_0.conv1 weights (canonical OIHW fp32 [32][3][3][3]) -> A fragments of v_mfma_f32_16x16x32_f16 for the fused first
+// block (conv3x3_ws.h, C0F): [half c][plane][lane][8]; lane l holds output channel 16 c + (l & 15), operand slots
+// 8 (l >> 4) .. +7 of the K = 32 order [dy 0: (dx,ch) 0..7][dy 1: 0..7][dy 2: 0..7][(dx,ch) = 8 of dy 0, 1, 2][0 x 5].
+__global__ void conv0_pack_kernel(const float* __restrict__ w, const float* __restrict__ mult, half_t* __restrict__ out) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;      // (c, plane, lane)
+  if (u >= 2 * 2 * 64) return;
+  const int lane = u & 63, pl = (u >> 6) & 1, c = u >> 7;
+  const int co = 16 * c + (lane & 15), kq = lane >> 4;
+  half8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int dy = -1, j = 0;
+    if (kq < 3) { dy = kq; j = i; } else if (i < 3) { dy = i; j = 8; }
+    float v = 0.f;
+    if (dy >= 0) { const int dx = j / 3, ch = j - 3 * dx; v = w[((co * 3 + ch) * 3 + dy) * 3 + dx] * mult[co]; }
+    const half_t hi = (half_t)v;
+    r[i] = pl == 0 ? hi : (half_t)(v - (float)hi);
+  }
+  *(half8*)(out + (size_t)u * 8) = r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Input conversion -> [N][1][H][W][P][8] fp16 (one channel block of 8, channels 3..7 zero).
 //   fmt 0: float32 NCHW RGB in [0,1]                    (model(img_tensor), infer_two_stage_burr.py:292-295)

@@ -70,6 +70,12 @@ struct ConvArgs {
   int rule;              // UNETPP_RULE_*
   float t_cable, t_tape, bg_margin, ct_margin;
   unsigned* status;      // engine's sticky range flags (ST_*), see range_flag
+  // fused first ConvBlock (conv3x3_ws.h, C0F): the caller's input tensor and conv0_0.conv1's packed weights
+  const void* raw_in;    // float32 [N,3,H,W] (raw_fmt 0) or uint8 [N,H,W,3] BGR (raw_fmt 1)
+  int raw_fmt;
+  const half_t* c1w;     // [half 2][plane 2][lane 64][8]: A fragments of v_mfma_f32_16x16x32_f16, see conv0_pack_kernel
+  const float* c1_scale; // [32]
+  const float* c1_bias;  // [32]
 #ifdef UNETPP_WS_DBG
   int dbg;               // measurement builds only: phases of conv3x3_ws_kernel switched off (results are garbage)
 #endif

@@ -30,7 +30,7 @@
 
 namespace unetpp {
 
-template <int P, bool UPF>
+template <int P, bool UPF, bool C0F = false>
 struct WsCfg {
   static constexpr int NT = 512, NCONS = 4, NPROD = 4, MW = 4;
   static constexpr int TH = NCONS * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
@@ -44,7 +44,11 @@ struct WsCfg {
   static constexpr int LSH = TH / 2 + 2, LSW = TW / 2 + 2, LS_PX = LSH * LSW, LS_REC = P * 32;
   static constexpr int LS_PIECES = (LS_PX * LS_REC + 1023) / 1024, LS_BYTES = UPF ? LS_PIECES * 1024 : 0;
   static constexpr int LS_ITERS = (LS_PIECES + NPROD - 1) / NPROD;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 2 * LS_BYTES;
+  // C0F (fused first ConvBlock, see the kernel): two input patches (TH+4) x (TW+4) x RGB float32 (+ 64 zero bytes)
+  static constexpr int PATCH_H = TH + 4, PATCH_W = TW + 4, PATCH_FLOATS = PATCH_H * PATCH_W * 3;
+  static constexpr int PATCH_BYTES = C0F ? ((PATCH_FLOATS * 4 + 64 + 255) / 256) * 256 : 0;
+  static constexpr int C0_GROUPS = (NHALO + 15) / 16, C0_ITERS = (C0_GROUPS + NPROD - 1) / NPROD;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 2 * LS_BYTES + 2 * PATCH_BYTES;
   // interpolation items: 2x2 halo blocks x channel quads
   static constexpr int BLK_Y = (TH + 2) / 2, BLK_X = HALO_W / 2, UP_ITEMS = BLK_Y * BLK_X * 4;
   static constexpr int UP_ROUNDS = (UP_ITEMS + NPROD * 64 - 1) / (NPROD * 64);
@@ -187,9 +191,20 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
   }
 }
 
-template <int P, bool POOL, bool HEAD, bool UPF>
+// C0F = the whole first ConvBlock in one launch (reference unetpp.py:68,104 conv0_0 = relu(bn(conv(relu(bn(conv(x)))))),
+// with preprocess_image's BGR->RGB, /255, HWC->CHW of infer_two_stage_burr.py:122-127 when the input is uint8): the
+// PRODUCERS compute conv0_0.conv1 (3 -> 32 channels, K = 27) themselves, straight from the caller's input tensor, into
+// the two halo images the consumers' conv0_0.conv2 reads -- x0_0a, the float32->fp16 input copy and two launches are
+// gone.  Per tile: a (16+4) x (32+4) x RGB float32 patch goes to LDS (prefetched one tile ahead); per chunk (16 of the
+// 32 conv1 channels) every producer wave takes 16-pixel groups of the 18 x 34 halo: it gathers each pixel's 27 patch
+// values as the B operand of v_mfma_f32_16x16x32_f16 (K = 32: [dy][dx,ch] order, 5 zero slots), multiplies by the
+// packed conv1 weights (hi/lo split, three MFMAs as everywhere), applies scale/bias/ReLU, writes zeros for halo pixels
+// outside the image (conv2's padding) and stores the hi/lo quads into the halo image.  The two conv2 weight slabs
+// stay in LDS for the whole launch.
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
-  using C = WsCfg<P, UPF>;
+  using C = WsCfg<P, UPF, C0F>;
+  static_assert(!C0F || (!UPF && !HEAD && P == 2), "fused first block: exact mode, no other fusion in the loader");
   constexpr int NT = C::NT, MW = C::MW, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
   constexpr int KC = C::KC, KG = C::KG, BN = C::BN, PPP = C::PPP;
   static_assert(!(POOL && HEAD) && !(UPF && (POOL || HEAD)), "one fused extra per kernel");
@@ -223,7 +238,212 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     x0 = tx * TW; y0 = ty * TH;
   };
   if (slot >= total_tiles) return;                       // whole workgroup: no barrier has been executed yet
-  __syncthreads();                                       // sb_lds / head_lds visible
+
+  // ---- C0F: patch loader (producer lanes) and the once-per-launch part of the producers' work
+  typedef __attribute__((ext_vector_type(4))) float float4v;
+  const int plane_id = tid - C::NCONS * 64;              // 0..255 among the producer lanes (negative: a consumer lane)
+  constexpr int PATCH_ELEMS = C::PATCH_FLOATS, PATCH_LOADS = C0F ? (PATCH_ELEMS + C::NPROD * 64 - 1) / (C::NPROD * 64) : 1;
+  const int patch_base = 2 * C::BUF_BYTES + 2 * C::LS_BYTES;
+  // patch element e of this lane (e = plane_id + 256 i): which image sample it is (row, col, ch relative to the patch
+  // origin) and where it goes in the LDS image [row][col][RGB]; fixed for the whole launch.
+  //   float32 NCHW: lanes walk a plane's rows (coalesced);  uint8 NHWC BGR: lanes walk the bytes of a row, RGB = BGR reversed
+  int pe_rc[PATCH_LOADS], pe_idx[PATCH_LOADS];          // (row << 16) | (col << 2) | plane-or-byte, LDS float index or -1
+  if (C0F) {
+#pragma unroll
+    for (int i = 0; i < PATCH_LOADS; ++i) {
+      const int e = plane_id + i * (C::NPROD * 64);
+      int row, col, cs, idx;
+      if (a.raw_fmt == 0) {
+        const int ch = e / (C::PATCH_H * C::PATCH_W), rem = e - ch * (C::PATCH_H * C::PATCH_W);
+        row = rem / C::PATCH_W; col = rem - row * C::PATCH_W; cs = ch; idx = rem * 3 + ch;
+      } else {
+        row = e / (C::PATCH_W * 3); const int b = e - row * (C::PATCH_W * 3);
+        col = b / 3; cs = b - col * 3; idx = (row * C::PATCH_W + col) * 3 + (2 - cs);
+      }
+      pe_rc[i] = (row << 16) | (col << 2) | cs;
+      pe_idx[i] = (e < PATCH_ELEMS && plane_id >= 0) ? idx : -1;
+    }
+  }
+  // values of the patch of tile (n, y0, x0): image pixel (y0 - 2 + row, x0 - 2 + col), 0 outside the image (buffer
+  // loads: an out-of-range offset reads back 0, no branches); uint8 input: /255 (preprocess_image)
+  auto patch_fetch = [&](int n, int y0, int x0, float (&val)[PATCH_LOADS]) {
+    const size_t img = (size_t)H * W * 3;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.raw_in + (size_t)n * img * (a.raw_fmt == 0 ? 4 : 1)), 0, (int)(img * (a.raw_fmt == 0 ? 4 : 1)), 0x00020000);
+    bool beyond = false;
+#pragma unroll
+    for (int i = 0; i < PATCH_LOADS; ++i) {
+      const int gy = y0 - 2 + (pe_rc[i] >> 16), gx = x0 - 2 + ((pe_rc[i] >> 2) & 0x3fff), cs = pe_rc[i] & 3;
+      const bool ok = pe_idx[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      float v;
+      if (a.raw_fmt == 0) {
+        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? ((cs * H + gy) * W + gx) * 4 : (int)0x80000000, 0, 0));
+      } else {
+        const unsigned char b8 = __builtin_amdgcn_raw_buffer_load_b8(rs, ok ? (gy * W + gx) * 3 + cs : (int)0x80000000, 0, 0);
+        v = __fdiv_rn((float)b8, 255.0f);
+      }
+      beyond |= !(fabsf(v) <= F16_MAX);
+      val[i] = v;
+    }
+    // a float32 input beyond the fp16 range (or a NaN) cannot enter the hi/lo planes unchanged: report it, clamp it
+    if (__builtin_amdgcn_ballot_w64(beyond)) {
+      bool nan = false;
+#pragma unroll
+      for (int i = 0; i < PATCH_LOADS; ++i) { nan |= val[i] != val[i]; val[i] = __builtin_amdgcn_fmed3f(val[i], -F16_MAX, F16_MAX); }
+      range_flag(a.status, beyond, nan);
+    }
+  };
+  auto patch_store = [&](int buf, const float (&val)[PATCH_LOADS]) {      // LDS image [row][col][RGB] float32
+    float* pd = (float*)(smem + patch_base + buf * C::PATCH_BYTES);
+#pragma unroll
+    for (int i = 0; i < PATCH_LOADS; ++i)
+      if (pe_idx[i] >= 0) pd[pe_idx[i]] = val[i];
+  };
+  if (C0F && wave >= C::NCONS) {
+    // conv2's two weight slabs: resident for the whole launch (buffer c holds chunk c)
+    constexpr int SL_IT = (2 * C::SLAB_PIECES + C::NPROD - 1) / C::NPROD;
+#pragma unroll
+    for (int it = 0; it < SL_IT; ++it) {
+      const int piece = (wave - C::NCONS) + it * C::NPROD;
+      if (piece < 2 * C::SLAB_PIECES) {
+        const int c = piece / C::SLAB_PIECES, pc = piece - c * C::SLAB_PIECES;
+        glds16((const char*)a.wpk + (size_t)c * C::SLAB_BYTES + pc * 1024, lane * 16,
+               lds_base + c * C::BUF_BYTES + C::HALO_BYTES + pc * 1024);
+      }
+    }
+    // the zero words behind each patch (operand slots 27..31 of a pixel read them) and the first tile's patch
+    if (plane_id < 32) {
+      *(float*)(smem + patch_base + PATCH_ELEMS * 4 + (plane_id & 15) * 4 + (plane_id >> 4) * C::PATCH_BYTES) = 0.f;
+    }
+    int n0, y00, x00;
+    decode(slot, n0, y00, x00);
+    float pv[PATCH_LOADS];
+    patch_fetch(n0, y00, x00, pv);
+    patch_store(0, pv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();                                       // sb_lds / head_lds (C0F: slabs, first patch) visible
+
+  if (C0F && wave >= C::NCONS) {
+    // =============================================================== producers, fused first block
+    const int pw = wave - C::NCONS;
+#ifndef UNETPP_C0_PRIO
+#define UNETPP_C0_PRIO 1
+#endif
+    // the matrix pipe serves the older (consumer) wave first: without a higher priority the producers' few MFMAs wait
+    // until the consumers stall
+    if (UNETPP_C0_PRIO) __builtin_amdgcn_s_setprio(UNETPP_C0_PRIO);
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const int pxl = lane & 15, kq = lane >> 4;
+    // packed conv1 weights: A fragments of this lane (row = output channel pxl of the half, k = 8 kq .. 8 kq + 7)
+    half8 wa_h[2], wa_l[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      wa_h[c] = *(const half8*)(a.c1w + ((size_t)(c * 2 + 0) * 64 + lane) * 8);
+      wa_l[c] = *(const half8*)(a.c1w + ((size_t)(c * 2 + 1) * 64 + lane) * 8);
+    }
+    // scale / bias of conv1's channels 16 c + 4 kq + r
+    float sc1[2][4], bi1[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc1[c][r] = a.c1_scale[16 * c + 4 * kq + r]; bi1[c][r] = a.c1_bias[16 * c + 4 * kq + r]; }
+    // operand slot i of a pixel at patch position (hy, hx): byte offset relative to patch[(hy)][hx][0]
+    //   kq < 3: row hy + kq, floats 0..7 of the 9 (dx, ch) values;  kq == 3: float 8 of rows hy, hy+1, hy+2, then zeros
+    int koff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (kq < 3) koff[i] = (kq * C::PATCH_W * 3 + i) * 4;
+      else koff[i] = i < 3 ? (i * C::PATCH_W * 3 + 8) * 4 : -1;            // -1: the zero words behind the patch
+    }
+    int g = 0;
+    for (int tile = slot; tile < total_tiles; tile += G) {
+      int n, y0, x0;
+      decode(tile, n, y0, x0);
+      const int tbuf = ((tile - slot) / G) & 1;                          // patch buffer of this tile
+      const char* patch = smem + patch_base + tbuf * C::PATCH_BYTES;
+      const int zero_off = PATCH_ELEMS * 4;
+#pragma unroll
+      for (int c = 0; c < 2; ++c, ++g) {                 // unrolled: c indexes register arrays
+        // prefetch the next tile's patch into registers at the start of chunk 0, park it in LDS at the end of chunk 0
+        float pv[PATCH_LOADS];
+        const int ntile = tile + G;
+        const bool have_next = c == 0 && ntile < total_tiles;
+        if (have_next) {
+          int n2, y2, x2;
+          decode(ntile, n2, y2, x2);
+          patch_fetch(n2, y2, x2, pv);
+        }
+        char* himg = smem + c * C::BUF_BYTES;
+        float vmax = 0.f;
+        // groups in batches of GB: all operand reads of a batch first, then its MFMAs, then its epilogues, so that the
+        // LDS latency and the three dependent MFMAs of one group hide behind the other groups' work (patch reads and
+        // halo-image writes go through the same LDS pointer: the compiler would not reorder them by itself)
+#ifndef UNETPP_C0_GB
+#define UNETPP_C0_GB 2
+#endif
+        constexpr int GB = UNETPP_C0_GB;
+        static_assert(C::C0_ITERS % GB == 0, "group batches");
+        // this lane's pixel of group pw + 4 it: hp = 16 (pw + 4 it) + pxl, advanced by 64 halo pixels per group
+        int hy = (pw * 16 + pxl) / HALO_W, hx = (pw * 16 + pxl) - hy * HALO_W;
+#pragma nounroll                                        // (unrolled, the per-group index math is hoisted out of the tile loop: spills)
+        for (int b0 = 0; b0 < C::C0_ITERS; b0 += GB) {
+          float bv[GB][8];
+          int ghy[GB], ghx[GB];
+#pragma unroll
+          for (int k = 0; k < GB; ++k) {
+            ghy[k] = hy; ghx[k] = hx;
+            const int hyc = min(hy, TH + 1);                  // the last group runs past the halo: any valid address
+            const int pix_off = (hyc * C::PATCH_W + hx) * 12;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bv[k][i] = *(const float*)(patch + (koff[i] >= 0 ? pix_off + koff[i] : zero_off + 4 * i));
+            hy += 1; hx += 64 - HALO_W;                        // + 64 pixels = one row and 30 columns
+            if (hx >= HALO_W) { hx -= HALO_W; hy += 1; }
+          }
+          f32x4 acc[GB];
+#pragma unroll
+          for (int k = 0; k < GB; ++k) {
+            unsigned bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_pack2(bv[k][2 * i], bv[k][2 * i + 1], bh[i], bl[i]);
+            const half8 xh = __builtin_bit_cast(half8, (u32x4){bh[0], bh[1], bh[2], bh[3]});
+            const half8 xl = __builtin_bit_cast(half8, (u32x4){bl[0], bl[1], bl[2], bl[3]});
+            acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xl, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_l[c], xh, acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xh, acc[k], 0, 0, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < GB; ++k) {
+            // lane: pixel pxl of the group, channels 16 c + 4 kq + r.  Halo pixels outside the image are conv2's zero padding.
+            const bool valid = ghy[k] < TH + 2;
+            const int hp = ghy[k] * HALO_W + ghx[k];
+            const int gy = y0 - 1 + ghy[k], gx = x0 - 1 + ghx[k];
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = inside ? fmaxf(acc[k][r] * sc1[c][r] + bi1[c][r], 0.f) : 0.f;
+              vmax = fmaxf(vmax, v[r]);
+            }
+            unsigned oh0, oh1, ol0, ol1;
+            split_pack2(fminf(v[0], F16_MAX), fminf(v[1], F16_MAX), oh0, ol0);
+            split_pack2(fminf(v[2], F16_MAX), fminf(v[3], F16_MAX), oh1, ol1);
+            if (valid) {
+              char* dst = himg + (hp / PPP) * 1024 + ((kq >> 1) * PPP + hp % PPP) * 16 + (kq & 1) * 8;
+              *(u32x2*)dst = (u32x2){oh0, oh1};
+              *(u32x2*)(dst + KG * PPP * 16) = (u32x2){ol0, ol1};
+            }
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
+        if (have_next) patch_store(tbuf ^ 1, pv);
+        lds_barrier();                                    // chunk g published; the consumers have left the other image
+      }
+    }
+    return;
+  }
 
   if (wave >= C::NCONS) {
     // =============================================================== producers

@@ -58,6 +58,7 @@ struct ConvLayer {
   int lvl = 0;
   int in = -1, in2 = -1, out = -1, pool = -1;   // tensor ids; in2: second source of the virtual concat
   bool do_pool = false;
+  bool c0f = false;             // conv0_0.conv2 computing conv0_0.conv1 itself from the caller's input (conv3x3_ws.h, C0F)
   bool upf = false;             // in2 is the LOW-resolution tensor: the loader does the bilinear x2 itself (no `up` tensor)
   size_t w_off = 0, b_off = 0;  // float offsets inside the canonical blob payload
   int KC = 16, NW = 1, MW = 2, WAVES = 8;
@@ -131,6 +132,8 @@ struct unetpp_engine {
   hipEvent_t ev_start = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
   // frame glue: per-axis resize tables on the device, keyed by (kind, n_src, n_dst); kind 0 = linear, 1 = nearest
   std::map<std::tuple<int, int, int>, void*> resize_tabs;
+  half_t* c1w = nullptr;          // fused first block: conv0_0.conv1 as MFMA A fragments (conv0_pack_kernel)
+  int c0f_conv1 = -1;             // index of conv0_0.conv1 in `convs` when the first block is fused, else -1
   bool use_ws = true;             // wave-specialised kernel for the Cout = 32 layers (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
 };
@@ -237,22 +240,23 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 }
 
 // wave-specialised kernel for the Cout = 32 layers (conv3x3_ws.h): 16-row tiles, one persistent workgroup per CU
-template <int P, bool POOL, bool HEAD, bool UPF>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
-  using C = WsCfg<P, UPF>;
+  using C = WsCfg<P, UPF, C0F>;
   a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = 1;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   const int total = a.N * a.tiles_x * a.tiles_y;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
-  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF>;
+  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, hipStream_t s) {
+hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
   if (P != 2 || a.Cout != 32 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
+  if (c0f) return (pool && !head && !upf && a.nchunks == 2) ? launch_ws_k<2, true, false, false, true>(cx, a, s) : hipErrorInvalidValue;
   if (upf) return launch_ws_k<2, false, false, true>(cx, a, s);
   if (head) return launch_ws_k<2, false, true, false>(cx, a, s);
   if (pool) return launch_ws_k<2, true, false, false>(cx, a, s);
@@ -370,7 +374,7 @@ struct Builder {
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
   }
-  int conv(const std::string& name, int cin_real, int in, int in2, int out, bool pool_to = false, int pool = -1) {
+  int conv(const std::string& name, int cin_real, int in, int in2, int out, bool pool_to = false, int pool = -1, bool emit_op = true) {
     ConvLayer L;
     L.name = name; L.cin_real = cin_real; L.in = in; L.in2 = in2; L.out = out; L.pool = pool; L.do_pool = pool_to;
     L.cout = e->tensors[out].C; L.lvl = e->tensors[out].lvl;
@@ -381,7 +385,7 @@ struct Builder {
     L.nchunks = (c0 + L.KC - 1) / L.KC + c1 / L.KC;
     e->convs.push_back(L);
     Op op; op.kind = OP_CONV; op.idx = (int)e->convs.size() - 1;
-    e->ops.push_back(op);
+    if (emit_op) e->ops.push_back(op);
     return op.idx;
   }
   void convt(const std::string& name, int in, int out) {
@@ -403,7 +407,10 @@ struct Builder {
 };
 
 void build_nested(unetpp_engine* e, Builder& b) {
-  Op cv; cv.kind = OP_CONVERT; e->ops.push_back(cv);
+  // exact mode: the first ConvBlock runs as ONE launch from the caller's tensor (no input copy, no conv0_0.conv1 launch,
+  // no x0_0a tensor): conv3x3_ws.h, C0F.  UNETPP_NO_C0F=1 keeps the three launches (A/B measurements).
+  const bool c0f = e->P == 2 && e->use_ws && !getenv("UNETPP_NO_C0F");
+  if (!c0f) { Op cv; cv.kind = OP_CONVERT; e->ops.push_back(cv); }
   e->t_in8 = b.tensor("in8", 8, 0);
   int x[5], xa[5], pooled[4], up[4], d[4], da[4];
   for (int l = 0; l < 5; ++l) {
@@ -413,8 +420,10 @@ void build_nested(unetpp_engine* e, Builder& b) {
     x[l] = b.tensor(nm, NB[l], l);
     if (l < 4) pooled[l] = b.tensor(std::string(nm) + "p", NB[l], l + 1);
     snprintf(nm, sizeof nm, "conv%d_0", l);
-    b.conv(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->t_in8 : pooled[l - 1], -1, xa[l]);
-    b.conv(std::string(nm) + ".conv2", NB[l], xa[l], -1, x[l], l < 4, l < 4 ? pooled[l] : -1);
+    const int c1 = b.conv(std::string(nm) + ".conv1", l == 0 ? 3 : NB[l - 1], l == 0 ? e->t_in8 : pooled[l - 1], -1, xa[l], false, -1,
+                          !(c0f && l == 0));
+    const int c2 = b.conv(std::string(nm) + ".conv2", NB[l], xa[l], -1, x[l], l < 4, l < 4 ? pooled[l] : -1);
+    if (c0f && l == 0) { e->convs[c2].c0f = true; e->c0f_conv1 = c1; }
   }
   for (int l = 3; l >= 0; --l) {
     char nm[32], tn[32];
@@ -569,6 +578,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     tsc[i] = total; total += align_up(T.cout * sizeof(float), 256);
     tmu[i] = total; total += align_up(T.cout * sizeof(float), 256);
   }
+  const size_t c1w_off = total; total += 4096;
   const size_t status_off = total; total += 256;
   hipError_t st = hipMalloc((void**)&e->arena, total);
   if (st == hipSuccess) {
@@ -582,6 +592,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   }
   e->arena_bytes = total;
   e->d_status = (unsigned*)(e->arena + status_off);
+  e->c1w = (half_t*)(e->arena + c1w_off);
   e->blob = (float*)(e->arena + blob_off);
   for (size_t i = 0; i < e->convs.size(); ++i) {
     e->convs[i].wpk = (half_t*)(e->arena + wpk_off[i]);
@@ -632,6 +643,10 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
                        L.cout, P, L.KC, BN, L.nchunks, L.wpk, units);
+  }
+  if (e->c0f_conv1 >= 0) {
+    const ConvLayer& L1 = e->convs[e->c0f_conv1];
+    hipLaunchKernelGGL(conv0_pack_kernel, dim3(1), dim3(256), 0, s, e->blob + L1.w_off, L1.mult, e->c1w);
   }
   for (auto& T : e->convts) {
     const float* w = e->blob + T.w_off;
@@ -779,6 +794,12 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
         a.status = e->d_status;
+        if (L.c0f) {     // the first block reads the caller's tensor itself
+          const ConvLayer& L1 = e->convs[e->c0f_conv1];
+          a.raw_in = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
+          a.raw_fmt = in_format == UNETPP_IN_F32_NCHW ? 0 : 1;
+          a.c1w = e->c1w; a.c1_scale = L1.scale; a.c1_bias = e->blob + L1.b_off;
+        }
 #ifdef UNETPP_WS_DBG
         { const char* d = getenv("UNETPP_WS_DBG"); a.dbg = d ? atoi(d) : 0; }
 #endif
@@ -789,6 +810,10 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         double px = (double)nb * H * W;
         double flops = 2.0 * px * L.cout * L.cin_real * 9;
         double bytes = px * P * 2.0 * (t0.C + (L.upf ? c1 / 4.0 : c1) + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+        if (L.c0f) {     // conv0_0.conv1 rides along: its flops, the raw input instead of x0_0a
+          flops += 2.0 * px * 32 * 3 * 9;
+          bytes += px * (in_format == UNETPP_IN_F32_NCHW ? 12.0 : 3.0) - px * P * 2.0 * t0.C;
+        }
         if (head) {
           a.head_w = e->blob + e->head_w_off; a.head_b = e->blob + e->head_b_off; a.head_C = C;
           a.logits = lg; a.mask = mk; a.cable = cb; a.tape = tpe;
@@ -801,10 +826,10 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
         const bool ws = e->use_ws && P == 2 && L.cout == 32 && (L.in2 < 0 || L.upf);
         char lbl[160];
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? "true" : "false");
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s%s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? "true" : "false", L.c0f ? ", true" : "");
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s%s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? ", true" : "");
         Lx.run(lbl, flops, bytes, [&] {
-          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, s)
+          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
       } else if (op.kind == OP_UP) {
