@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunetpp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["unetpp_abi.hip"]
-HEADERS = ["conv3x3_mfma.h", "conv3x3_ws.h", "convt2x2_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include", "unetpp.h")]
+HEADERS = ["conv3x3_mfma.h", "conv3x3_ws.h", "tapmm_ws.h", "convt2x2_mfma.h", "aux_kernels.h", os.path.join("..", "..", "include", "unetpp.h")]
 
 # every symbol include/unetpp.h declares
 ABI_SYMBOLS = [

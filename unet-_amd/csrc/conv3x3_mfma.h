@@ -71,6 +71,7 @@ struct ConvArgs {
   float t_cable, t_tape, bg_margin, ct_margin;
   unsigned* status;      // engine's sticky range flags (ST_*), see range_flag
   // fused first ConvBlock (conv3x3_ws.h, C0F): the caller's input tensor and conv0_0.conv1's packed weights
+  const float* zinit;    // ZINIT: [N][Cout/32][H*W][32] fp32 accumulator start values (tapmm_ws.h), else unused
   const void* raw_in;    // float32 [N,3,H,W] (raw_fmt 0) or uint8 [N,H,W,3] BGR (raw_fmt 1)
   int raw_fmt;
   const half_t* c1w;     // [half 2][plane 2][lane 64][8]: A fragments of v_mfma_f32_16x16x32_f16, see conv0_pack_kernel
@@ -256,7 +257,9 @@ template <int P, bool HEAD> constexpr bool conv_single_stage() { return HEAD && 
 // fetching a materialised `up` tensor: per tile and chunk, <= 10 x 18 low-res pixel records arrive by LDS-DMA two
 // chunks ahead, and while chunk c multiplies, the waves build chunk c+1's halo image from them (VALU + ds_write
 // beside the MFMAs).  The `up` tensor is never written or read: -2.4 GB of the 12.7 GB step at level 0.
-template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false, bool UPF = false>
+// ZINIT: the accumulators of a tile start from a.zinit (the low-resolution half of a decoder conv, tapmm_ws.h)
+// instead of zero; K then runs over the skip channels only.
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false, bool UPF = false, bool ZINIT = false>
 __global__ __launch_bounds__(WAVES * 64, (conv_single_stage<P, HEAD>() ? 2 : 1))
 void conv3x3_bias_relu_kernel(ConvArgs a) {
   using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>(), UPF>;
@@ -525,9 +528,24 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
-      for (int j = 0; j < NW; ++j)
+      for (int j = 0; j < NW; ++j) {
+        if (ZINIT) {      // lane = pixel, registers 4q..4q+3 = channels 8q + 4h + (0..3) of the 32-block: four 16-byte loads
+          typedef __attribute__((ext_vector_type(4))) float f32x4;
+          const int gy = cur_y0 + wave * MW + m, gx = cur_x0 + (lane & 31);
+          const bool in = gy < H && gx < W;
+          const float* zp = a.zinit + (((size_t)cur_n * (a.Cout >> 5) + ((cur_ct * BN + j * 32) >> 5)) * ((size_t)H * W) + (size_t)gy * W + gx) * 32 + 4 * (lane >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+          for (int q = 0; q < 4; ++q) {
+            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            if (in) z4 = *(const f32x4*)(zp + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = z4[i];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+        }
+      }
 
     const int next_tile = tile + (int)gridDim.x;
     const bool have_next = next_tile < total_tiles;

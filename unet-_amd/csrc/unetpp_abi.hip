@@ -32,6 +32,7 @@
 #include "conv3x3_mfma.h"
 #include "conv3x3_ws.h"
 #include "convt2x2_mfma.h"
+#include "tapmm_ws.h"
 
 using namespace unetpp;
 
@@ -58,6 +59,9 @@ struct ConvLayer {
   int lvl = 0;
   int in = -1, in2 = -1, out = -1, pool = -1;   // tensor ids; in2: second source of the virtual concat
   bool do_pool = false;
+  int zt = -1;                  // tensor id of the fp32 accumulator start values (tapmm_ws.h): K = skip channels only
+  int y_t = -1, low_t = -1;     // tapmm: fp32 Y tensor and the low-res input it is computed from
+  half_t* tapw = nullptr;       // tapmm: packed weights of the up channels
   bool c0f = false;             // conv0_0.conv2 computing conv0_0.conv1 itself from the caller's input (conv3x3_ws.h, C0F)
   bool upf = false;             // in2 is the LOW-resolution tensor: the loader does the bilinear x2 itself (no `up` tensor)
   size_t w_off = 0, b_off = 0;  // float offsets inside the canonical blob payload
@@ -78,7 +82,7 @@ struct ConvTLayer {
   float* mult = nullptr;
 };
 
-enum OpKind { OP_CONVERT, OP_CONV, OP_UP, OP_CONVT, OP_HEAD };
+enum OpKind { OP_CONVERT, OP_CONV, OP_UP, OP_CONVT, OP_HEAD, OP_TAPMM, OP_UPSUM };
 struct Op {
   OpKind kind;
   int idx = -1;            // conv / convT index, or (OP_UP) source tensor id
@@ -224,7 +228,7 @@ hipError_t allow_full_lds(const void* kernel, int device) {
   return st;
 }
 
-template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD, bool UPF = false>
+template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD, bool UPF = false, bool ZINIT = false>
 hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>(), UPF>;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
@@ -232,7 +236,7 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   const int per_cu = std::max(1, std::min(2, (160 * 1024) / lds));
   dim3 grid((unsigned)std::min(total, cx.num_cus * per_cu));
-  auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD, UPF>;
+  auto k = conv3x3_bias_relu_kernel<P, KC, NW, MW, WAVES, POOL, HEAD, UPF, ZINIT>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
@@ -269,6 +273,10 @@ hipError_t launch_conv_cfg(const LaunchCtx& cx, const ConvArgs& a, bool pool, bo
     if (upf) return (pool || head) ? hipErrorInvalidValue : launch_conv_k<P, KC, NW, MW, WAVES, false, false, true>(cx, a, s);
   }
   if (upf) return hipErrorInvalidValue;
+  if constexpr (P == 2 && NW == 2 && MW == 2 && KC == 16) {     // accumulators start from the low-resolution half (tapmm_ws.h)
+    if (a.zinit) return (pool || head) ? hipErrorInvalidValue : launch_conv_k<P, KC, NW, MW, WAVES, false, false, false, true>(cx, a, s);
+  }
+  if (a.zinit) return hipErrorInvalidValue;
   if constexpr (NW == 1) {
     if (head) return launch_conv_k<P, KC, NW, MW, WAVES, false, true>(cx, a, s);
   }
@@ -302,7 +310,7 @@ hipError_t launch_conv(const LaunchCtx& cx, int P, const ConvLayer& L, int mw, c
 // workgroups, each with half the matrix work per K-chunk.  Every output is still accumulated chunk by chunk, tap by
 // tap in the same order, so the result is bitwise the same whichever tile height ran (tested).
 int small_grid_rows(const ConvLayer& L, int num_cus, int nb, int H, int W, bool head) {
-  if (L.do_pool || head || L.upf || L.NW == 1 || L.MW != 2) return L.MW;
+  if (L.do_pool || head || L.upf || L.zt >= 0 || L.NW == 1 || L.MW != 2) return L.MW;
   const int tiles = nb * ((W + 31) / 32) * ((H + 15) / 16) * (L.cout / (32 * L.NW));
   return tiles < num_cus ? 1 : L.MW;
 }
@@ -374,6 +382,15 @@ struct Builder {
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
   }
+  int tensor_raw(const std::string& name, size_t bytes_per_px, int lvl) {      // e.g. an fp32 tensor
+    Tensor t;
+    t.name = name; t.C = 0; t.lvl = lvl; t.off = act;
+    const unetpp_config& c = e->cfg;
+    size_t px = (size_t)e->mb * (c.max_h >> lvl) * (c.max_w >> lvl);
+    act += align_up(px * bytes_per_px, 256);
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+  }
   int conv(const std::string& name, int cin_real, int in, int in2, int out, bool pool_to = false, int pool = -1, bool emit_op = true) {
     ConvLayer L;
     L.name = name; L.cin_real = cin_real; L.in = in; L.in2 = in2; L.out = out; L.pool = pool; L.do_pool = pool_to;
@@ -433,6 +450,25 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // the low-res tensor (conv3x3_mfma.h, UPF) -- no upsample launch, no `up` tensor.  UNETPP_NO_UPF=1 keeps the
     // separate kernel (A/B measurements).
     const bool upf = l == 0 && !getenv("UNETPP_NO_UPF");
+    // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
+    // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
+    const char* tl = getenv("UNETPP_TAPMM");
+    const bool tapmm = e->P == 2 && l >= 1 && strchr(tl ? tl : "23", '0' + l) != nullptr;
+    if (tapmm) {
+      snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
+      const int yt = b.tensor_raw(std::string(tn) + "y", (size_t)9 * NB[l] * 4, l + 1);
+      const int zt = b.tensor_raw(std::string(tn) + "z", (size_t)NB[l] * 4, l);
+      da[l] = b.tensor(std::string(tn) + "a", NB[l], l);
+      d[l] = b.tensor(tn, NB[l], l);
+      { Op op; op.kind = OP_TAPMM; op.idx = (int)e->convs.size(); e->ops.push_back(op); }     // the conv pushed next
+      { Op op; op.kind = OP_UPSUM; op.idx = (int)e->convs.size(); e->ops.push_back(op); }
+      const int ci = b.conv(std::string(nm) + ".conv1", NB[l] + NB[l + 1], x[l], -1, da[l]);
+      ConvLayer& L = e->convs[ci];
+      L.zt = zt; L.y_t = yt; L.low_t = low;
+      L.nchunks = NB[l] / L.KC;                         // K over the skip channels only
+      b.conv(std::string(nm) + ".conv2", NB[l], da[l], -1, d[l]);
+      continue;
+    }
     if (!upf) up[l] = b.tensor(std::string(tn) + "u", NB[l + 1], l);
     da[l] = b.tensor(std::string(tn) + "a", NB[l], l);
     d[l] = b.tensor(tn, NB[l], l);
@@ -571,6 +607,13 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     sc_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
     mu_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
   }
+  std::vector<size_t> tapw_off(e->convs.size(), 0);
+  for (size_t i = 0; i < e->convs.size(); ++i) {
+    ConvLayer& L = e->convs[i];
+    if (L.zt < 0) continue;
+    const int cup = L.cin_real - e->tensors[L.in].C;
+    tapw_off[i] = total; total += align_up((size_t)9 * L.cout * cup * P * sizeof(half_t), 256);
+  }
   std::vector<size_t> twpk(e->convts.size()), tsc(e->convts.size()), tmu(e->convts.size());
   for (size_t i = 0; i < e->convts.size(); ++i) {
     ConvTLayer& T = e->convts[i];
@@ -598,6 +641,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     e->convs[i].wpk = (half_t*)(e->arena + wpk_off[i]);
     e->convs[i].scale = (float*)(e->arena + sc_off[i]);
     e->convs[i].mult = (float*)(e->arena + mu_off[i]);
+    if (e->convs[i].zt >= 0) e->convs[i].tapw = (half_t*)(e->arena + tapw_off[i]);
   }
   for (size_t i = 0; i < e->convts.size(); ++i) {
     e->convts[i].wpk = (half_t*)(e->arena + twpk[i]);
@@ -643,6 +687,13 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
                        L.cout, P, L.KC, BN, L.nchunks, L.wpk, units);
+  }
+  for (auto& L : e->convs) {
+    if (L.zt < 0) continue;
+    const int cs = e->tensors[L.in].C, cup = L.cin_real - cs;
+    const long long units = (long long)9 * L.cout * cup * P / 8;
+    hipLaunchKernelGGL(tapw_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, e->blob + L.w_off, L.mult, L.cout, cs,
+                       cup, L.tapw, units);
   }
   if (e->c0f_conv1 >= 0) {
     const ConvLayer& L1 = e->convs[e->c0f_conv1];
@@ -794,6 +845,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.pool_out = L.do_pool ? tp(L.pool) : nullptr;
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
         a.status = e->d_status;
+        a.zinit = L.zt >= 0 ? (const float*)tp(L.zt) : nullptr;
         if (L.c0f) {     // the first block reads the caller's tensor itself
           const ConvLayer& L1 = e->convs[e->c0f_conv1];
           a.raw_in = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
@@ -808,8 +860,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.tiles_x = (W + 31) / 32; a.tiles_y = (H + TH - 1) / TH;
         a.nct = L.cout / (32 * L.NW); a.nchunks = L.nchunks;
         double px = (double)nb * H * W;
-        double flops = 2.0 * px * L.cout * L.cin_real * 9;
+        double flops = 2.0 * px * L.cout * (L.zt >= 0 ? t0.C : L.cin_real) * 9;
         double bytes = px * P * 2.0 * (t0.C + (L.upf ? c1 / 4.0 : c1) + (head ? 0 : L.cout)) + (L.do_pool ? px / 4 * P * 2.0 * L.cout : 0.0) + (double)L.cout * L.cin_real * 9 * 2.0 * P;
+        if (L.zt >= 0) bytes += px * L.cout * 4.0 - (double)L.cout * (L.cin_real - t0.C) * 9 * 2.0 * P;
         if (L.c0f) {     // conv0_0.conv1 rides along: its flops, the raw input instead of x0_0a
           flops += 2.0 * px * 32 * 3 * 9;
           bytes += px * (in_format == UNETPP_IN_F32_NCHW ? 12.0 : 3.0) - px * P * 2.0 * t0.C;
@@ -832,6 +885,36 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
+      } else if (op.kind == OP_TAPMM || op.kind == OP_UPSUM) {
+        const ConvLayer& L = e->convs[op.idx];
+        const int H = h >> L.lvl, W = w >> L.lvl;
+        const int cs = e->tensors[L.in].C, cup = L.cin_real - cs;
+        if (op.kind == OP_TAPMM) {
+          TapmmArgs t{};
+          t.low = tp(L.low_t); t.wpk = L.tapw; t.y = (float*)tp(L.y_t);
+          t.N = nb; t.hw = (H >> 1) * (W >> 1); t.K = cup; t.Nv = 9 * L.cout;
+          const int tiles = nb * ((t.hw + TapmmCfg::TM - 1) / TapmmCfg::TM) * (t.Nv / TapmmCfg::TN);
+          const double M = (double)nb * t.hw;
+          char lbl[96];
+          snprintf(lbl, sizeof lbl, "%s.up-gemm|tapmm_ws_kernel", L.name.c_str());
+          Lx.run(lbl, 2.0 * M * cup * t.Nv, M * cup * 2.0 * P + M * t.Nv * 4.0 + (double)t.Nv * cup * 2.0 * P, [&] {
+            hipError_t st = allow_full_lds((const void*)tapmm_ws_kernel, e->cfg.device);
+            if (st != hipSuccess) return st;
+            hipLaunchKernelGGL(tapmm_ws_kernel, dim3((unsigned)std::min(tiles, e->num_cus)), dim3(TapmmCfg::NT), TapmmCfg::LDS_BYTES, s, t);
+            return hipSuccess;
+          });
+        } else {
+          UpsumArgs u{};
+          u.y = (const float*)tp(L.y_t); u.z = (float*)tp(L.zt); u.N = nb; u.H = H; u.W = W; u.Cout = L.cout;
+          const unsigned blocks = (unsigned)(((W + UpsumCfg::TW - 1) / UpsumCfg::TW) * ((H + UpsumCfg::TH - 1) / UpsumCfg::TH) * (L.cout / 32) * nb);
+          const double px = (double)nb * H * W;
+          char lbl[96];
+          snprintf(lbl, sizeof lbl, "%s.up-sum|upsum_kernel", L.name.c_str());
+          Lx.run(lbl, px * L.cout * 9 * 8.0, px / 4 * 9 * L.cout * 4.0 + px * L.cout * 4.0, [&] {
+            hipLaunchKernelGGL(upsum_kernel, dim3(blocks), dim3(256), UpsumCfg::LDS_BYTES, s, u);
+            return hipSuccess;
+          });
+        }
       } else if (op.kind == OP_UP) {
         const Tensor& low = e->tensors[op.idx];
         const Tensor& dst = e->tensors[op.out];
