@@ -98,3 +98,36 @@ def test_frame_preprocess_matches_reference_semantics(syn):
     assert x.shape == (2, 3, 16, 32) and x.dtype == np.float32
     assert x[1, 0, 3, 5] == np.float32(f[1, 3, 5, 2]) / np.float32(255.0)      # R plane comes from BGR index 2
     assert np.array_equal(x, syn.frames_to_chw_f32(f))
+
+
+def _ac_rows(n_out):
+    """float32 index math of the bilinear x2 upsample, align_corners=True, exactly as the kernels compute it
+    (upsample2x_kernel / conv3x3_ws.h / tapmm_ws.h): src = dst * (in-1)/(out-1) in float32, i0 = int(src)."""
+    n_in = n_out // 2
+    s = np.float32(n_in - 1) / np.float32(n_out - 1) if n_in > 1 else np.float32(0)
+    f = (s * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+    i0 = np.minimum(f.astype(np.int32), n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    return s, i0, i1
+
+
+@pytest.mark.parametrize("n_out", list(range(16, 1200, 16)) + [2048, 4096])
+def test_fused_upsample_index_claims(n_out):
+    """The geometry the fused-upsample loaders rely on (conv3x3_mfma.h UPF, conv3x3_ws.h, tapmm_ws.h upsum_kernel):
+    for tile origins at multiples of 16 (rows) / 32 (columns) of an n_out-long axis,
+      * a 16-row (32-column) tile with its 1-pixel halo touches at most 10 (18) low-res rows (columns) counted from
+        floor(s * max(origin - 1, 0)), and the 16+2 rows of an upsum tile at most 11;
+      * the two image rows (columns) of every 2x2 halo block — an odd one and the even one after it — share their low-res
+        corner pair, so one producer lane can serve the block from four records."""
+    s, i0, i1 = _ac_rows(n_out)
+    for tile, lim in ((16, 10), (32, 18)):
+        for o in range(0, n_out, tile):
+            lo, hi = max(o - 1, 0), min(o + tile, n_out - 1)
+            base = int(np.float32(s * np.float32(lo)))
+            assert i0[lo:hi + 1].min() >= base
+            assert i1[lo:hi + 1].max() - base + 1 <= lim
+    for o in range(0, n_out, 16):                                   # upsum_kernel: rows o-1 .. o+16 of a 16-row tile
+        lo, hi = max(o - 1, 0), min(o + 16, n_out - 1)
+        assert i1[lo:hi + 1].max() - int(np.float32(s * np.float32(lo))) + 1 <= 11
+    odd = np.arange(1, n_out - 1, 2)
+    assert np.array_equal(i0[odd], i0[odd + 1]) and np.array_equal(i1[odd], i1[odd + 1])

@@ -30,6 +30,9 @@ struct TapmmArgs {
   const half_t* wpk;     // [Nv/128][K/16][4 v-tiles][P][2][32][8]  (tapw_pack_kernel)
   float* y;              // [N][Nv/32][h*w][32] fp32 raw accumulators
   int N, hw, K, Nv;      // low-res pixels per image, input channels, virtual channels (9 * Cout)
+#ifdef UNETPP_WS_DBG
+  int dbg;               // measurement builds: 1 no DMA, 2 no MFMA, 4 no Y stores
+#endif
 };
 
 struct TapmmCfg {
@@ -64,7 +67,6 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
     q0 = mt * C::TM;
   };
   if (slot >= total_tiles) return;
-
   if (wave >= C::NCONS) {
     // =============================================================== producers
     const int pw = wave - C::NCONS;
@@ -75,6 +77,9 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
     int in_, iq0, ivt;
     decode(it_tile, in_, iq0, ivt);
     auto issue = [&](int ring) {
+#ifdef UNETPP_WS_DBG
+      if (a.dbg & 1) { if (++it_s == nst) { it_s = 0; it_tile += G; if (it_tile < total_tiles) decode(it_tile, in_, iq0, ivt); } return; }
+#endif
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.low + (size_t)in_ * (a.K / 16) * a.hw * 32), 0, (int)((a.K / 16) * blk_bytes), 0x00020000);
       const unsigned dstA = lds_base + ring * C::STAGE_BYTES;
@@ -133,6 +138,9 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
   };
   float16v acc[C::MT][C::NTL];
   auto run_mfma = [&](const Frag& f) {
+#ifdef UNETPP_WS_DBG
+    if (a.dbg & 2) return;
+#endif
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -173,6 +181,9 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       ++g;
     }
+#ifdef UNETPP_WS_DBG
+    if (a.dbg & 4) { if (acc[0][0][0] == 12345.f) a.y[0] = 1.f; continue; }
+#endif
     // ---- store the raw accumulators: Y[n][v/32][q][32], lane = pixel, registers 4q'..4q'+3 = channels 8q' + 4h + (0..3)
     const int h = lane >> 5;
 #pragma unroll

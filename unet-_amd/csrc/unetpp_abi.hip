@@ -879,8 +879,10 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
         const bool ws = e->use_ws && P == 2 && L.cout == 32 && (L.in2 < 0 || L.upf);
         char lbl[160];
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s%s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? "true" : "false", L.c0f ? ", true" : "");
-        else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s%s>", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, L.do_pool ? "true" : "false", head ? "true" : "false", L.upf ? ", true" : "");
+        // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
+        auto tf = [](bool v) { return v ? "true" : "false"; };
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f));
+        else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
@@ -893,6 +895,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           TapmmArgs t{};
           t.low = tp(L.low_t); t.wpk = L.tapw; t.y = (float*)tp(L.y_t);
           t.N = nb; t.hw = (H >> 1) * (W >> 1); t.K = cup; t.Nv = 9 * L.cout;
+#ifdef UNETPP_WS_DBG
+          { const char* d = getenv("UNETPP_TAPMM_DBG"); t.dbg = d ? atoi(d) : 0; }
+#endif
           const int tiles = nb * ((t.hw + TapmmCfg::TM - 1) / TapmmCfg::TM) * (t.Nv / TapmmCfg::TN);
           const double M = (double)nb * t.hw;
           char lbl[96];
