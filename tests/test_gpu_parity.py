@@ -612,3 +612,30 @@ def test_config5_1024_batch8_against_reference_fixture(torch_cuda, syn, oracle):
         mi, li = model.segment(xu8[i:i + 1], return_logits=True)
         assert torch.equal(li, logits[i:i + 1]) and torch.equal(mi, mask[i:i + 1])
     assert model.status() == 0
+
+
+@pytest.mark.parametrize("env", [{"UNETPP_NO_WS": "1"}, {"UNETPP_NO_UPF": "1"}, {"UNETPP_NO_C0F": "1"}, {"UNETPP_TAPMM": "none"},
+                                 {"UNETPP_TAPMM": "123"}, {"UNETPP_NO_WS": "1", "UNETPP_NO_UPF": "1", "UNETPP_TAPMM": "none"}])
+def test_alternative_kernel_paths_agree(env, torch_cuda, syn, oracle, monkeypatch):
+    """Every fusion has a switch that restores the separate kernels (read when an engine is created; used for A/B
+    measurements): lock-step instead of wave-specialised Cout=32 kernels, separate level-0 upsample, unfused first block,
+    decoder conv1 without / with the low-resolution GEMM at more levels.  Each combination must pass the same parity
+    bar as the default path and agree with it to rounding (the summation order differs, the arithmetic does not)."""
+    torch = torch_cuda
+    frames = syn.make_frames_u8(2, 96, 160, "smooth", 41)
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    base, sd = make_model(3, True, 2, "exact", syn, 2, (96, 160))
+    ref = oracle.torch_forward(sd, syn.frames_to_chw_f32(frames))
+    ref_mask, _, _ = oracle.masks_from_logits(ref)
+    m0, l0 = base.segment(x, return_logits=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt, _ = make_model(3, True, 2, "exact", syn, 2, (96, 160))
+    m1, l1 = alt.segment(x, return_logits=True)
+    torch.cuda.synchronize()
+    for name, lg, mk in (("default", l0, m0), (str(env), l1, m1)):
+        err, flips, unexplained = report(lg.cpu().numpy(), mk.cpu().numpy(), ref, ref_mask, oracle)
+        print(f"{name}: max|dlogit|={err:.3e} flips={flips}")
+        assert err < 2e-5 and unexplained == 0
+    assert float((l0 - l1).abs().max()) < 2e-5
+    assert alt.status() == 0 and base.status() == 0
