@@ -615,11 +615,11 @@ def test_config5_1024_batch8_against_reference_fixture(torch_cuda, syn, oracle):
 
 
 @pytest.mark.parametrize("env", [{"UNETPP_NO_WS": "1"}, {"UNETPP_NO_UPF": "1"}, {"UNETPP_NO_C0F": "1"}, {"UNETPP_TAPMM": "none"},
-                                 {"UNETPP_TAPMM": "123"}, {"UNETPP_NO_WS": "1", "UNETPP_NO_UPF": "1", "UNETPP_TAPMM": "none"}])
+                                 {"UNETPP_TAPMM": "3"}, {"UNETPP_NO_WS": "1", "UNETPP_NO_UPF": "1", "UNETPP_TAPMM": "none"}])
 def test_alternative_kernel_paths_agree(env, torch_cuda, syn, oracle, monkeypatch):
     """Every fusion has a switch that restores the separate kernels (read when an engine is created; used for A/B
     measurements): lock-step instead of wave-specialised Cout=32 kernels, separate level-0 upsample, unfused first block,
-    decoder conv1 without / with the low-resolution GEMM at more levels.  Each combination must pass the same parity
+    decoder conv1 without the low-resolution GEMM / with it at level 3 only.  Each combination must pass the same parity
     bar as the default path and agree with it to rounding (the summation order differs, the arithmetic does not)."""
     torch = torch_cuda
     frames = syn.make_frames_u8(2, 96, 160, "smooth", 41)

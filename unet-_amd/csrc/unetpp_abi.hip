@@ -453,7 +453,9 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
     // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
     const char* tl = getenv("UNETPP_TAPMM");
-    const bool tapmm = e->P == 2 && l >= 1 && strchr(tl ? tl : "23", '0' + l) != nullptr;
+    // (the GEMM's 128-wide virtual-channel tiles need 9 * Cout % 128 == 0: levels 2 and 3; at level 1 the fp32
+    // side tensors would be 0.9 GB per step and the path measured slower anyway)
+    const bool tapmm = e->P == 2 && l >= 1 && (9 * NB[l]) % TapmmCfg::TN == 0 && strchr(tl ? tl : "23", '0' + l) != nullptr;
     if (tapmm) {
       snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
       const int yt = b.tensor_raw(std::string(tn) + "y", (size_t)9 * NB[l] * 4, l + 1);
