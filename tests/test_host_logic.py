@@ -115,12 +115,12 @@ def _ac_rows(n_out):
 def test_fused_upsample_index_claims(n_out):
     """The geometry the fused-upsample loaders rely on (conv3x3_mfma.h UPF, conv3x3_ws.h, tapmm_ws.h upsum_kernel):
     for tile origins at multiples of 16 (rows) / 32 (columns) of an n_out-long axis,
-      * a 16-row (32-column) tile with its 1-pixel halo touches at most 10 (18) low-res rows (columns) counted from
+      * an 8- / 16-row (32-column) tile with its 1-pixel halo touches at most 6 / 10 (18) low-res rows (columns) counted from
         floor(s * max(origin - 1, 0)), and the 16+2 rows of an upsum tile at most 11;
       * the two image rows (columns) of every 2x2 halo block — an odd one and the even one after it — share their low-res
         corner pair, so one producer lane can serve the block from four records."""
     s, i0, i1 = _ac_rows(n_out)
-    for tile, lim in ((16, 10), (32, 18)):
+    for tile, lim in ((8, 6), (16, 10), (32, 18)):
         for o in range(0, n_out, tile):
             lo, hi = max(o - 1, 0), min(o + tile, n_out - 1)
             base = int(np.float32(s * np.float32(lo)))

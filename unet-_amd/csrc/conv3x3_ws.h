@@ -30,11 +30,15 @@
 
 namespace unetpp {
 
-template <int P, bool UPF, bool C0F = false>
+// NW x MW = 32-channel blocks x rows per consumer wave: 1 x 4 (Cout = 32, 16-row tiles) or 2 x 2 (Cout = 64, 8-row
+// tiles: the same 108 MFMAs per chunk and wave; the 37 KB weight slab of 64 output channels leaves LDS room for two
+// 8-row halo images only).
+template <int P, bool UPF, bool C0F = false, int NW_ = 1, int MW_ = 4>
 struct WsCfg {
-  static constexpr int NT = 512, NCONS = 4, NPROD = 4, MW = 4;
+  static constexpr int NT = 512, NCONS = 4, NPROD = 4, MW = MW_, NW = NW_;
   static constexpr int TH = NCONS * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
-  static constexpr int KC = 16, KG = 2, BN = 32;
+  static constexpr int KC = 16, KG = 2, BN = 32 * NW;
+  static_assert(MW % 2 == 0 && NW * MW == 4, "108 MFMAs per chunk and consumer wave");
   static constexpr int U = P * KG, PPP = 64 / U;
   static constexpr int HALO_PIECES = (NHALO + PPP - 1) / PPP, HALO_BYTES = HALO_PIECES * 1024;
   static constexpr int HALO_ITERS = (HALO_PIECES + NPROD - 1) / NPROD;
@@ -201,10 +205,11 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
 // packed conv1 weights (hi/lo split, three MFMAs as everywhere), applies scale/bias/ReLU, writes zeros for halo pixels
 // outside the image (conv2's padding) and stores the hi/lo quads into the halo image.  The two conv2 weight slabs
 // stay in LDS for the whole launch.
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MWP = 4>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
-  using C = WsCfg<P, UPF, C0F>;
-  static_assert(!C0F || (!UPF && !HEAD && P == 2), "fused first block: exact mode, no other fusion in the loader");
+  using C = WsCfg<P, UPF, C0F, NW, MWP>;
+  static_assert(!C0F || (!UPF && !HEAD && P == 2 && NW == 1), "fused first block: exact mode, no other fusion in the loader");
+  static_assert(!HEAD || NW == 1, "the fused head needs all 32 channels of x0_4 in one 32-block");
   constexpr int NT = C::NT, MW = C::MW, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
   constexpr int KC = C::KC, KG = C::KG, BN = C::BN, PPP = C::PPP;
   static_assert(!(POOL && HEAD) && !(UPF && (POOL || HEAD)), "one fused extra per kernel");
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     }
   const int b_lane_off = ((lane >> 5) * BN + (lane & 31)) * 16;
   struct AFrag { half8 h[MW + 2], l[MW + 2]; };
-  struct BFrag { half8 h, l; };
+  struct BFrag { half8 h[NW], l[NW]; };
   auto load_a = [&](AFrag& f, const char* halo, int dx) {
 #pragma unroll
     for (int r = 0; r < MW + 2; ++r) {
@@ -707,20 +712,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
   };
   auto load_b = [&](BFrag& f, const char* slab, int tap) {
-    const int off = b_lane_off + tap * KG * BN * 16;
-    f.h = *(const half8*)(slab + off);
-    if (P == 2) f.l = *(const half8*)(slab + off + 9 * KC * BN * 2);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int off = b_lane_off + (tap * KG * BN + j * 32) * 16;
+      f.h[j] = *(const half8*)(slab + off);
+      if (P == 2) f.l[j] = *(const half8*)(slab + off + 9 * KC * BN * 2);
+    }
   };
-  float16v acc[MW];
+  float16v acc[MW][NW];
   auto run_mfma = [&](const AFrag& fa, const BFrag& fb, int dy) {
 #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-      if (P == 2) {
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h, fa.l[m + dy], acc[m], 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.l, fa.h[m + dy], acc[m], 0, 0, 0);
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        if (P == 2) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.l[m + dy], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.l[j], fa.h[m + dy], acc[m][j], 0, 0, 0);
+        }
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.h[m + dy], acc[m][j], 0, 0, 0);
       }
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h, fa.h[m + dy], acc[m], 0, 0, 0);
-    }
   };
 
   int g = 0;
@@ -730,7 +740,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      for (int j = 0; j < NW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
     for (int c = 0; c < a.nchunks; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
       const char* halo = smem + (g & 1) * C::BUF_BYTES;
@@ -769,13 +781,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     }
     // ---- epilogue from registers, two row pairs; the producers are already filling the next tile's first chunk
 #ifdef UNETPP_WS_DBG
-    if (a.dbg & 256) { if (acc[0][0] == 12345.f && acc[3][5] == 7.f) a.status[1] = 1; continue; }
+    if (a.dbg & 256) { if (acc[0][0][0] == 12345.f && acc[MW - 1][NW - 1][5] == 7.f) a.status[1] = 1; continue; }
 #endif
 #pragma unroll
-    for (int m2 = 0; m2 < MW / 2; ++m2) {
-      const float16v pair[2] = {acc[2 * m2], acc[2 * m2 + 1]};
-      ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, 0, lane);
-    }
+    for (int m2 = 0; m2 < MW / 2; ++m2)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const float16v pair[2] = {acc[2 * m2][j], acc[2 * m2 + 1][j]};
+        ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, j * 32, lane);
+      }
   }
 }
 

@@ -138,6 +138,7 @@ struct unetpp_engine {
   std::map<std::tuple<int, int, int>, void*> resize_tabs;
   half_t* c1w = nullptr;          // fused first block: conv0_0.conv1 as MFMA A fragments (conv0_pack_kernel)
   int c0f_conv1 = -1;             // index of conv0_0.conv1 in `convs` when the first block is fused, else -1
+  bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
   bool use_ws = true;             // wave-specialised kernel for the Cout = 32 layers (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
 };
@@ -244,14 +245,14 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 }
 
 // wave-specialised kernel for the Cout = 32 layers (conv3x3_ws.h): 16-row tiles, one persistent workgroup per CU
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
-  using C = WsCfg<P, UPF, C0F>;
+  using C = WsCfg<P, UPF, C0F, NW, MW>;
   a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = 1;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   const int total = a.N * a.tiles_x * a.tiles_y;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
-  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F>;
+  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
@@ -259,7 +260,14 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
 }
 
 hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
-  if (P != 2 || a.Cout != 32 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
+  if (P != 2 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
+  if (a.Cout == 64) {      // 8-row tiles, two 32-channel blocks per consumer wave
+    if (head || c0f) return hipErrorInvalidValue;
+    if (upf) return launch_ws_k<2, false, false, true, false, 2, 2>(cx, a, s);
+    if (pool) return launch_ws_k<2, true, false, false, false, 2, 2>(cx, a, s);
+    return launch_ws_k<2, false, false, false, false, 2, 2>(cx, a, s);
+  }
+  if (a.Cout != 32) return hipErrorInvalidValue;
   if (c0f) return (pool && !head && !upf && a.nchunks == 2) ? launch_ws_k<2, true, false, false, true>(cx, a, s) : hipErrorInvalidValue;
   if (upf) return launch_ws_k<2, false, false, true>(cx, a, s);
   if (head) return launch_ws_k<2, false, true, false>(cx, a, s);
@@ -449,7 +457,7 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // Level 0 (Cout = 32: narrow tiles, HBM co-bound): the decoder conv interpolates its `up` channels itself from
     // the low-res tensor (conv3x3_mfma.h, UPF) -- no upsample launch, no `up` tensor.  UNETPP_NO_UPF=1 keeps the
     // separate kernel (A/B measurements).
-    const bool upf = l == 0 && !getenv("UNETPP_NO_UPF");
+    const bool upf = !getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && !getenv("UNETPP_NO_UPF1")));
     // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
     // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
     const char* tl = getenv("UNETPP_TAPMM");
@@ -583,6 +591,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   }
   e->cfg = *cfg;
   e->use_ws = !getenv("UNETPP_NO_WS");
+  e->ws64 = e->use_ws && !getenv("UNETPP_NO_WS64");
   e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
   e->nstreams = std::max(1, std::min(4, cfg->streams));
@@ -879,11 +888,11 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           head_done = true;
         }
         // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
-        const bool ws = e->use_ws && P == 2 && L.cout == 32 && (L.in2 < 0 || L.upf);
+        const bool ws = e->use_ws && P == 2 && (L.cout == 32 || (L.cout == 64 && e->ws64)) && (L.in2 < 0 || L.upf) && L.zt < 0;
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
         auto tf = [](bool v) { return v ? "true" : "false"; };
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f));
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout / 32, L.cout == 32 ? 4 : 2);
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
