@@ -483,10 +483,12 @@ def test_determinism_side_stream_and_threads(torch_cuda, syn):
         assert len(outs) == 5 and all(torch.equal(o, a) for o in outs)
 
 
-def test_small_grid_tiles_are_bitwise_the_same(torch_cuda, syn):
-    """Small batches run the pool-free layers with 8-row tiles (twice the workgroups), large ones with 16-row
-    tiles; a frame's logits must not depend on which tile height computed it."""
+def test_small_grid_tiles_are_bitwise_the_same(torch_cuda, syn, monkeypatch):
+    """The lock-step kernel (fast mode; exact mode with UNETPP_NO_WS=1) runs small batches' pool-free layers with 8-row
+    tiles (twice the workgroups) and large ones with 16-row tiles; a frame's logits must not depend on which tile
+    height computed it."""
     torch = torch_cuda
+    monkeypatch.setenv("UNETPP_NO_WS", "1")
     B, H, W = 16, 256, 256
     frames = syn.make_frames_u8(B, H, W, "smooth", 31)
     x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()

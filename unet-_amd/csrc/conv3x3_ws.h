@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W;
   const int tiles_img = a.tiles_x * a.tiles_y;
-  const int total_tiles = a.N * tiles_img;              // Cout == 32: one channel tile
+  const int total_tiles = a.N * tiles_img * a.nct;      // a.nct = Cout / BN channel tiles per pixel tile
   const int nch0 = (a.C0 + KC - 1) / KC;
   const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
 
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   // tile order as in conv3x3_bias_relu_kernel: an XCD (workgroups b, b+8, ...) walks a contiguous run of tiles
   const int G = (int)gridDim.x;
   const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  int dec_ct = 0;                                         // channel tile of the tile decoded last (role-local cursor)
   auto decode = [&](int t, int& n, int& y0, int& x0) {
+    dec_ct = t % a.nct; t /= a.nct;
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     n = t / a.tiles_y;
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       int n, y0, x0;
       decode(tile, n, y0, x0);
       setup_tile(n, y0, x0);
-      const char* wsrc = (const char*)a.wpk;
+      const char* wsrc = (const char*)a.wpk + (size_t)dec_ct * a.nchunks * C::SLAB_BYTES;
       for (int c = 0; c < a.nchunks; ++c, ++g) {
         const int buf = (g & 1) * C::BUF_BYTES;
 #ifdef UNETPP_WS_DBG
@@ -737,12 +739,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   for (int tile = slot; tile < total_tiles; tile += G) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
+    const int ct = dec_ct;
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
-      for (int j = 0; j < NW; ++j)
+      for (int j = 0; j < NW; ++j) {
+        if (a.zinit) {    // accumulators start from the low-resolution half of the layer (tapmm_ws.h); uniform branch
+          typedef __attribute__((ext_vector_type(4))) float f32x4;
+          const int gy = y0 + cw * MW + m, gx = x0 + (lane & 31);
+          const bool in = gy < H && gx < W;
+          const float* zp = a.zinit + (((size_t)n * (a.Cout >> 5) + ((ct * BN + j * 32) >> 5)) * ((size_t)H * W) + (size_t)gy * W + gx) * 32 + 4 * (lane >> 5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+          for (int q = 0; q < 4; ++q) {
+            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            if (in) z4 = *(const f32x4*)(zp + 8 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = z4[i];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+        }
+      }
     for (int c = 0; c < a.nchunks; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
       const char* halo = smem + (g & 1) * C::BUF_BYTES;
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const float16v pair[2] = {acc[2 * m2][j], acc[2 * m2 + 1][j]};
-        ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, j * 32, lane);
+        ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
       }
   }
 }

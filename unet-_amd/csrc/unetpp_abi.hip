@@ -138,6 +138,7 @@ struct unetpp_engine {
   std::map<std::tuple<int, int, int>, void*> resize_tabs;
   half_t* c1w = nullptr;          // fused first block: conv0_0.conv1 as MFMA A fragments (conv0_pack_kernel)
   int c0f_conv1 = -1;             // index of conv0_0.conv1 in `convs` when the first block is fused, else -1
+  int ws_max_cout = 512;          // largest Cout the 8-row wave-specialised tiles are used for (UNETPP_WS_MAX_COUT; measured: every layer gains 1-8 %)
   bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
   bool use_ws = true;             // wave-specialised kernel for the Cout = 32 layers (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
@@ -248,9 +249,9 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   using C = WsCfg<P, UPF, C0F, NW, MW>;
-  a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = 1;
+  a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
-  const int total = a.N * a.tiles_x * a.tiles_y;
+  const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
   auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
@@ -261,7 +262,7 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
 
 hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
   if (P != 2 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
-  if (a.Cout == 64) {      // 8-row tiles, two 32-channel blocks per consumer wave
+  if (a.Cout >= 64 && a.Cout % 64 == 0) {      // 8-row tiles, two 32-channel blocks per consumer wave, Cout / 64 channel tiles
     if (head || c0f) return hipErrorInvalidValue;
     if (upf) return launch_ws_k<2, false, false, true, false, 2, 2>(cx, a, s);
     if (pool) return launch_ws_k<2, true, false, false, false, 2, 2>(cx, a, s);
@@ -592,6 +593,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   e->cfg = *cfg;
   e->use_ws = !getenv("UNETPP_NO_WS");
   e->ws64 = e->use_ws && !getenv("UNETPP_NO_WS64");
+  if (const char* mc = getenv("UNETPP_WS_MAX_COUT")) e->ws_max_cout = atoi(mc);
   e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
   e->nstreams = std::max(1, std::min(4, cfg->streams));
@@ -888,11 +890,11 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           head_done = true;
         }
         // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
-        const bool ws = e->use_ws && P == 2 && (L.cout == 32 || (L.cout == 64 && e->ws64)) && (L.in2 < 0 || L.upf) && L.zt < 0;
+        const bool ws = e->use_ws && P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
         auto tf = [](bool v) { return v ? "true" : "false"; };
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout / 32, L.cout == 32 ? 4 : 2);
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2);
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
