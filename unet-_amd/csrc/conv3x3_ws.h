@@ -52,7 +52,12 @@ struct WsCfg {
   static constexpr int PATCH_H = TH + 4, PATCH_W = TW + 4, PATCH_FLOATS = PATCH_H * PATCH_W * 3;
   static constexpr int PATCH_BYTES = C0F ? ((PATCH_FLOATS * 4 + 64 + 255) / 256) * 256 : 0;
   static constexpr int C0_GROUPS = (NHALO + 15) / 16, C0_ITERS = (C0_GROUPS + NPROD - 1) / NPROD;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 2 * LS_BYTES + 2 * PATCH_BYTES;
+  // HANDOFF (layers whose producers only move data): each consumer wave leaves half of its finished accumulators
+  // (two of its four 32x32 results, 8 KB) in LDS and the producer wave of the same number runs their epilogue while
+  // the consumers already multiply the next tile -- two waves per SIMD issue the epilogue's VALU work instead of one.
+  static constexpr bool HANDOFF = !UPF && !C0F;
+  static constexpr int STG_WAVE = 2 * 16 * 64 * 4, STG_BYTES = HANDOFF ? NCONS * STG_WAVE : 0;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 2 * LS_BYTES + 2 * PATCH_BYTES + STG_BYTES;
   // interpolation items: 2x2 halo blocks x channel quads
   static constexpr int BLK_Y = (TH + 2) / 2, BLK_X = HALO_W / 2, UP_ITEMS = BLK_Y * BLK_X * 4;
   static constexpr int UP_ROUNDS = (UP_ITEMS + NPROD * 64 - 1) / (NPROD * 64);
@@ -623,12 +628,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
     };
 
+    // HANDOFF: the epilogue of the accumulator pair consumer wave `pw` left in LDS for the previous tile
+    const int stg_base = 2 * C::BUF_BYTES + 2 * C::LS_BYTES + 2 * C::PATCH_BYTES;
+    int hn = 0, hy0 = 0, hx0 = 0, hct = 0;
+    bool have_handoff = false;
+    auto handoff_epilogue = [&]() {
+      const char* st = smem + stg_base + pw * C::STG_WAVE + lane * 16;
+      float16v pair[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          typedef __attribute__((ext_vector_type(4))) float f32x4;
+          const f32x4 v4 = *(const f32x4*)(st + (i * 4 + q) * 1024);
+          pair[i][4 * q] = v4[0]; pair[i][4 * q + 1] = v4[1]; pair[i][4 * q + 2] = v4[2]; pair[i][4 * q + 3] = v4[3];
+        }
+      // the pair is rows (2, 3) of the wave's four rows (MW = 4) or the second 32-channel block of its two rows (MW = 2)
+      const int gy0 = hy0 + pw * MW + (MW == 4 ? 2 : 0);
+      const int cbase = hct * BN + (MW == 4 ? 0 : 32);
+      ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
+    };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
     for (int tile = slot; tile < total_tiles; tile += G) {
       int n, y0, x0;
       decode(tile, n, y0, x0);
       setup_tile(n, y0, x0);
       const char* wsrc = (const char*)a.wpk + (size_t)dec_ct * a.nchunks * C::SLAB_BYTES;
+      const int tile_ct = dec_ct;
       for (int c = 0; c < a.nchunks; ++c, ++g) {
         const int buf = (g & 1) * C::BUF_BYTES;
 #ifdef UNETPP_WS_DBG
@@ -672,9 +698,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 128))
 #endif
+        if (C::HANDOFF && c == 1 && have_handoff) handoff_epilogue();     // previous tile's pair: published by the barrier behind chunk 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
         lds_barrier();                                    // chunk g published; the consumers have left buffer (g+1) & 1
       }
+      hn = n; hy0 = y0; hx0 = x0; hct = tile_ct; have_handoff = true;
+    }
+    if (C::HANDOFF && a.nchunks >= 2) {                   // (a one-chunk tile has no second barrier to publish the pair)
+      lds_barrier();                                      // the consumers' last pair is in LDS
+      if (have_handoff) handoff_epilogue();
     }
     return;
   }
@@ -805,10 +837,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     for (int m2 = 0; m2 < MW / 2; ++m2)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        const float16v pair[2] = {acc[2 * m2][j], acc[2 * m2 + 1][j]};
-        ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
+        const bool give = C::HANDOFF && a.nchunks >= 2 && (MW == 4 ? m2 == 1 : j == 1);      // this pair goes to producer wave cw
+        if (give) {
+          char* st = smem + (2 * C::BUF_BYTES + 2 * C::LS_BYTES + 2 * C::PATCH_BYTES) + cw * C::STG_WAVE + lane * 16;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              typedef __attribute__((ext_vector_type(4))) float f32x4;
+              const float16v& v = acc[2 * m2 + i][j];
+              *(f32x4*)(st + (i * 4 + q) * 1024) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
+        } else {
+          const float16v pair[2] = {acc[2 * m2][j], acc[2 * m2 + 1][j]};
+          ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
+        }
       }
   }
+  if (C::HANDOFF && a.nchunks >= 2) lds_barrier();        // the last handed-over pair is in LDS
 }
 
 }  // namespace unetpp
