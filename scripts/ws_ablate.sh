@@ -7,7 +7,8 @@
 set -e
 cd "$(dirname "$0")/.."
 H=$(python -c 'from unet_amd import _lib; print(_lib.source_hash())')
-(cd unet-_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DUNETPP_WS_DBG=1 -DUNETPP_SRC_HASH=\"$H\" -o ../libunetpp_hip.so unetpp_abi.hip)
+FLAGS=$(python -c 'from unet_amd import _lib; print(" ".join(_lib.CXXFLAGS))')
+(cd unet-_amd/csrc && /opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DUNETPP_WS_DBG=1 -DUNETPP_SRC_HASH=\"$H\" -o ../libunetpp_hip.so unetpp_abi.hip)
 for d in "$@"; do
   echo "UNETPP_WS_DBG=$d"
   UNETPP_ALLOW_DBG_LIB=1 UNETPP_WS_DBG=$d timeout -k 10 120 python scripts/layer_profile.py exact 2>&1 | grep "conv0_0\|conv0_4" || true

@@ -48,10 +48,17 @@ class Outputs(ctypes.Structure):
                 ("ct_margin", ctypes.c_float)]
 
 
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of float operations into v_pk_mul_f32 / v_pk_fma_f32, and a packed
+# fp32 instruction issued beside another wave's MFMA stream on the same SIMD takes 26-58 cycles instead of 5-7
+# (scripts/microbench/valu_beside_mfma.hip) -- the loader waves of the wave-specialised kernels run exactly there.
+CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"]
+
+
 def source_hash() -> str:
-    """Digest of every file the library is compiled from; baked into the binary (unetpp_version() ends in
-    'src:<hash>') so that a .so built from other sources is recognised wherever it travels."""
+    """Digest of every file the library is compiled from and of the compiler flags; baked into the binary
+    (unetpp_version() ends in 'src:<hash>') so that a .so built from other sources is recognised wherever it travels."""
     h = hashlib.sha256()
+    h.update(" ".join(CXXFLAGS).encode() + b"\0")
     for rel in sorted(SOURCES + HEADERS):
         with open(os.path.join(CSRC, rel), "rb") as f:
             h.update(rel.encode() + b"\0" + f.read() + b"\0")
@@ -91,7 +98,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not hipcc:
         raise RuntimeError("hipcc not found: cannot build libunetpp_hip.so")
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"      # several ranks may build at once: write aside, then rename atomically
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DUNETPP_SRC_HASH="{source_hash()}"',
+    cmd = [hipcc] + CXXFLAGS + ["-shared", "-fPIC", f'-DUNETPP_SRC_HASH="{source_hash()}"',
            "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd).replace(tmp, LIB_PATH), flush=True)

@@ -79,6 +79,7 @@ struct ConvArgs {
   const float* c1_bias;  // [32]
 #ifdef UNETPP_WS_DBG
   int dbg;               // measurement builds only: phases of conv3x3_ws_kernel switched off (results are garbage)
+  unsigned long long* stamps;   // or nullptr: [workgroup][role][8] cycle sums of the phases of one wave per role
 #endif
 };
 

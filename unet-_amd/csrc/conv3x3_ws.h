@@ -466,12 +466,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     constexpr unsigned OOB = 0x80000000u;                // beyond num_records: the buffer load returns zeros
     constexpr int ITERS = C::HALO_ITERS;
     // tile-invariant: halo pixel / unit of this lane in each of its DMA pieces (as in conv3x3_bias_relu_kernel)
-    const int my_u = lane / PPP;
+    int my_u = lane / PPP;
+#ifdef UNETPP_WS_DBG
+    if (a.dbg & 16384) my_u = lane % C::U;               // timing experiment: a pixel's units on neighbouring lanes (results garbage)
+#endif
     const int my_pl = my_u / KG, my_k8 = (my_u % KG) * 8;
     int hyx[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int hp = (pw + it * C::NPROD) * PPP + lane % PPP;
+      int hp = (pw + it * C::NPROD) * PPP + lane % PPP;
+#ifdef UNETPP_WS_DBG
+      if (a.dbg & 16384) hp = (pw + it * C::NPROD) * PPP + lane / C::U;
+#endif
       const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
       hyx[it] = (hp < C::NHALO) ? ((hy << 8) | hx) : -1;
     }
@@ -492,6 +498,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     int up_o00[UPR], up_o01[UPR], up_o10[UPR];          // staging offsets of the corners (ra,ca), (ra,cb), (rb,ca)
     float up_wx[UPR][4], up_wy[UPR][4];                  // {lx0, lx1} of the block's two columns, {ly0, ly1} of its two rows
     int up_dst[UPR];                                     // halo-image offset of the block's first pixel, -1 = no item
+    // A corner is only ever used as hi + lo, so the two 8-byte reads of a record may come in either order: the second
+    // 16 lanes of every 32-lane read group (blocks 4..7 of eight neighbouring blocks) fetch lo first.  With 64-byte
+    // records the first read then touches banks [16 rx, 16 rx + 8) in blocks 0..3 and [16 rx + 8, 16 rx + 16) in
+    // blocks 4..7 -- all 64 banks once, instead of every bank twice; two separate ds_read_b64 (2 LDS cycles each)
+    // also replace the ds_read2_b64 the compiler forms from a fixed +32 offset (8 cycles, banked modulo 32).
+    int rd_swap = (P == 2 && (lane & 16)) ? 32 : 0;
+#ifdef UNETPP_WS_DBG
+    if (a.dbg & 32) rd_swap = 0;
+#endif
     if (UPF) {
 #pragma unroll
       for (int r = 0; r < UPR; ++r) {
@@ -542,9 +557,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           const int yy1 = yy0 + (yy0 < Hs - 1 ? 1 : 0), xx1 = xx0 + (xx0 < Ws - 1 ? 1 : 0);
           const int ry0 = min(max(yy0 - ybase, 0), C::LSH - 1), ry1 = min(max(yy1 - ybase, 0), C::LSH - 1);
           const int rx0 = min(max(xx0 - xbase, 0), C::LSW - 1), rx1 = min(max(xx1 - xbase, 0), C::LSW - 1);
-          up_o00[r] = (ry0 * C::LSW + rx0) * C::LS_REC + q * 8;
-          up_o01[r] = (ry0 * C::LSW + rx1) * C::LS_REC + q * 8;
-          up_o10[r] = (ry1 * C::LSW + rx0) * C::LS_REC + q * 8;
+          up_o00[r] = (ry0 * C::LSW + rx0) * C::LS_REC + q * 8 + rd_swap;
+          up_o01[r] = (ry0 * C::LSW + rx1) * C::LS_REC + q * 8 + rd_swap;
+          up_o10[r] = (ry1 * C::LSW + rx0) * C::LS_REC + q * 8 + rd_swap;
           // Lanes of the second channel octet (q >= 2) take the block's two columns in the opposite order: at every
           // ds_write_b64 the two octets of a block then hit different pixels, hence different banks (conflict-free
           // stores into the [unit][pixel] halo image; in the same order the octets would collide 2-way).
@@ -562,6 +577,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
     };
 
+#ifdef UNETPP_WS_DBG
+    // stamps: [0] skip-chunk issue, [1] skip-chunk wait, [2] skip-chunk barrier, [3] up-chunk issue, [4] interpolation,
+    // [5] up-chunk wait, [6] up-chunk barrier, [7] tile setup; with dbg bit 32768 the interpolation is cut into
+    // [8] corner reads issued and landed, [9] arithmetic, [10] stores issued and retired (instead of [4])
+    unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; }
+#define WS_STAMP_IN(i) if (a.dbg & 32768) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WS_STAMP(i) __builtin_amdgcn_sched_barrier(0); }
+    unsigned long long st_t = 0;
+#else
+#define WS_STAMP(i) {}
+#define WS_STAMP_IN(i) {}
+#endif
     // all interpolation items of this lane for up-chunk c: staging buffer (c & 1) -> halo image.  Straight-line code
     // for all rounds (the LDS reads of every round are issued before the first value is needed; a lane without an
     // item in the last round computes on clamped addresses and skips only the stores).
@@ -575,10 +602,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         const int off[4] = {up_o00[r], up_o01[r], up_o10[r], o11};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#ifdef UNETPP_WS_DBG
+          if (a.dbg & 512) { hq[r][k] = (u32x2){0x3c003c00u, 0x3c003c00u}; lq[r][k] = (u32x2){0u, 0u}; continue; }
+#endif
           hq[r][k] = *(const u32x2*)(ls + off[k]);
-          if (P == 2) lq[r][k] = *(const u32x2*)(ls + off[k] + 32);
+          if (P == 2) lq[r][k] = *(const u32x2*)(ls + (off[k] ^ 32));
         }
       }
+      // LDS operations retire in order: a corner read issued behind a round's stores would only return after them
+      // (stores queue behind the consumers' fragment reads for hundreds of cycles), so every read goes out first.
+      __builtin_amdgcn_sched_barrier(0);
+      WS_STAMP_IN(8)
 #pragma unroll
       for (int r = 0; r < UPR; ++r) {
         float v[4][4];                                   // [pixel 2 * ky + kx][channel]
@@ -604,6 +638,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
             for (int ky = 0; ky < 2; ++ky) v[2 * ky + kx][e] = fmaf(up_wy[r][2 * ky + 1], t1, up_wy[r][2 * ky] * t0);
           }
         }
+        WS_STAMP_IN(9)
+#ifdef UNETPP_WS_DBG
+        if (a.dbg & 64) { if (v[0][0] == 12345.f && v[3][3] == 7.f && v[1][2] == 3.f && v[2][1] == 9.f) a.status[1] = 1; continue; }
+#endif
         if (up_dst[r] >= 0) {
           const int hp0 = up_dst[r] >> 2, q = up_dst[r] & 3;
 #pragma unroll
@@ -625,6 +663,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
               if (P == 2) *(u32x2*)(dst + KG * PPP * 16) = ol;
             }
         }
+        WS_STAMP_IN(10)
       }
     };
 
@@ -649,10 +688,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
     };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
+#ifdef UNETPP_WS_DBG
+    st_t = __builtin_readcyclecounter();
+#endif
     for (int tile = slot; tile < total_tiles; tile += G) {
       int n, y0, x0;
       decode(tile, n, y0, x0);
       setup_tile(n, y0, x0);
+      WS_STAMP(7)
       const char* wsrc = (const char*)a.wpk + (size_t)dec_ct * a.nchunks * C::SLAB_BYTES;
       const int tile_ct = dec_ct;
       for (int c = 0; c < a.nchunks; ++c, ++g) {
@@ -677,6 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           if (C::SLAB_PIECES % C::NPROD == 0 || piece < C::SLAB_PIECES)
             glds16(wsrc + (size_t)c * C::SLAB_BYTES + piece * 1024, lane * 16, lds_base + buf + C::HALO_BYTES + piece * 1024);
         }
+        if (!UPF) { WS_STAMP(0) }
         if (UPF) {
 #ifdef UNETPP_WS_DBG
           if (!(a.dbg & 2))
@@ -690,17 +734,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
                        lds_base + 2 * C::BUF_BYTES + ((c + 1) & 1) * C::LS_BYTES + piece * 1024);
             }
           }
+          if (c >= nch0) { WS_STAMP(3) } else { WS_STAMP(0) }
 #ifdef UNETPP_WS_DBG
           if (!(a.dbg & 1))
 #endif
           if (c >= nch0) up_rounds(c, buf);              // this chunk's halo image from the records that landed last iteration
+          if (c >= nch0) { WS_STAMP(4) } else { WS_STAMP(0) }
         }
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 128))
 #endif
         if (C::HANDOFF && c == 1 && have_handoff) handoff_epilogue();     // previous tile's pair: published by the barrier behind chunk 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        if (UPF && c >= nch0) { WS_STAMP(5) } else { WS_STAMP(1) }
         lds_barrier();                                    // chunk g published; the consumers have left buffer (g+1) & 1
+        if (UPF && c >= nch0) { WS_STAMP(6) } else { WS_STAMP(2) }
       }
       hn = n; hy0 = y0; hx0 = x0; hct = tile_ct; have_handoff = true;
     }
@@ -708,6 +756,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       lds_barrier();                                      // the consumers' last pair is in LDS
       if (have_handoff) handoff_epilogue();
     }
+#ifdef UNETPP_WS_DBG
+    if (a.stamps && pw == 0 && lane == 0)
+#pragma unroll
+      for (int i = 0; i < 11; ++i) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + i] = st_sum[i];
+#endif
     return;
   }
 
@@ -768,6 +821,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   };
 
   int g = 0;
+#ifdef UNETPP_WS_DBG
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [0] barrier, [1] chunk, [2] epilogue, [3] accumulator init
+  unsigned long long st_t = __builtin_readcyclecounter();
+#endif
   for (int tile = slot; tile < total_tiles; tile += G) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
@@ -793,8 +850,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         }
       }
+    WS_STAMP(3)
     for (int c = 0; c < a.nchunks; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
+      WS_STAMP(0)
       const char* halo = smem + (g & 1) * C::BUF_BYTES;
       const char* slab = halo + C::HALO_BYTES;
       // dx-major walk: the six halo rows of one column shift serve its three taps.  Fragments of the next tap
@@ -828,6 +887,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      WS_STAMP(1)
     }
     // ---- epilogue from registers, two row pairs; the producers are already filling the next tile's first chunk
 #ifdef UNETPP_WS_DBG
@@ -853,8 +913,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
         }
       }
+    WS_STAMP(2)
   }
   if (C::HANDOFF && a.nchunks >= 2) lds_barrier();        // the last handed-over pair is in LDS
+#ifdef UNETPP_WS_DBG
+  if (a.stamps && cw == 0 && lane == 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.stamps[((size_t)blockIdx.x * 2) * 16 + i] = st_sum[i];
+#endif
 }
+#undef WS_STAMP
 
 }  // namespace unetpp

@@ -867,6 +867,14 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         }
 #ifdef UNETPP_WS_DBG
         { const char* d = getenv("UNETPP_WS_DBG"); a.dbg = d ? atoi(d) : 0; }
+        static unsigned long long* stamp_buf = nullptr;
+        const char* stamp_layer = getenv("UNETPP_WS_STAMPS");      // layer name: print that launch's in-kernel phase times
+        const bool stamp_this = stamp_layer && L.name == stamp_layer;
+        if (stamp_this) {
+          if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, 1024 * 32 * 8);
+          (void)hipMemsetAsync(stamp_buf, 0, 1024 * 32 * 8, s);
+          a.stamps = stamp_buf;
+        }
 #endif
         const int mw = small_grid_rows(L, e->num_cus, nb, H, W, head);
         const int TH = L.WAVES * mw;
@@ -900,6 +908,22 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
+#ifdef UNETPP_WS_DBG
+        if (stamp_this && ws) {
+          static int printed = 0;
+          std::vector<unsigned long long> hs(1024 * 32);
+          (void)hipStreamSynchronize(s);
+          (void)hipMemcpy(hs.data(), stamp_buf, hs.size() * 8, hipMemcpyDeviceToHost);
+          if (printed++ == 3) {      // a warm launch
+            double sum[32] = {0};
+            int nwg = 0;
+            for (int b = 0; b < 1024; ++b) { if (!hs[b * 32 + 1] && !hs[b * 32 + 16]) continue; ++nwg; for (int i = 0; i < 32; ++i) sum[i] += (double)hs[b * 32 + i]; }
+            fprintf(stderr, "[stamps %s] %d workgroups, mean cycles per workgroup:\n  consumer: barrier %.0f  chunks %.0f  epilogue %.0f  init %.0f\n"
+                            "  producer: skip issue %.0f wait %.0f barrier %.0f | up issue %.0f interp %.0f (reads %.0f arithmetic %.0f split+stores %.0f) wait %.0f barrier %.0f | setup %.0f\n", L.name.c_str(), nwg,
+                    sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[16] / nwg, sum[17] / nwg, sum[18] / nwg, sum[19] / nwg, sum[20] / nwg, sum[24] / nwg, sum[25] / nwg, sum[26] / nwg, sum[21] / nwg, sum[22] / nwg, sum[23] / nwg);
+          }
+        }
+#endif
       } else if (op.kind == OP_TAPMM || op.kind == OP_UPSUM) {
         const ConvLayer& L = e->convs[op.idx];
         const int H = h >> L.lvl, W = w >> L.lvl;
