@@ -241,13 +241,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   // tile order as in conv3x3_bias_relu_kernel: an XCD (workgroups b, b+8, ...) walks a contiguous run of tiles
   const int G = (int)gridDim.x;
   const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
-  int dec_ct = 0;                                         // channel tile of the tile decoded last (role-local cursor)
+  // Tile number -> (channel tile, column, row, image).  A workgroup asks for its slot, then for tiles G apart (or the
+  // same tile again): only the first call divides, later ones add G's own decomposition with carries (wave-uniform
+  // scalar work; the six divisions per tile used to cost several hundred cycles in each role).
+  int dec_ct = 0, dec_tx = 0, dec_ty = 0, dec_n = 0, dec_t = -1;      // the tile decoded last (per-wave cursor)
+  int g_ct, g_tx, g_ty, g_n;
+  {
+    int t = G;
+    g_ct = t % a.nct; t /= a.nct;
+    g_tx = t % a.tiles_x; t /= a.tiles_x;
+    g_ty = t % a.tiles_y;
+    g_n = t / a.tiles_y;
+  }
   auto decode = [&](int t, int& n, int& y0, int& x0) {
-    dec_ct = t % a.nct; t /= a.nct;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    n = t / a.tiles_y;
-    x0 = tx * TW; y0 = ty * TH;
+    if (t != dec_t) {
+      if (dec_t >= 0 && t == dec_t + G) {
+        dec_ct += g_ct;
+        int carry = dec_ct >= a.nct ? 1 : 0;
+        dec_ct -= carry ? a.nct : 0;
+        dec_tx += g_tx + carry;
+        carry = dec_tx >= a.tiles_x ? 1 : 0;
+        dec_tx -= carry ? a.tiles_x : 0;
+        dec_ty += g_ty + carry;
+        carry = dec_ty >= a.tiles_y ? 1 : 0;
+        dec_ty -= carry ? a.tiles_y : 0;
+        dec_n += g_n + carry;
+      } else {
+        int u = t;
+        dec_ct = u % a.nct; u /= a.nct;
+        dec_tx = u % a.tiles_x; u /= a.tiles_x;
+        dec_ty = u % a.tiles_y;
+        dec_n = u / a.tiles_y;
+      }
+      dec_t = t;
+    }
+    n = dec_n; x0 = dec_tx * TW; y0 = dec_ty * TH;
   };
   if (slot >= total_tiles) return;                       // whole workgroup: no barrier has been executed yet
 
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     for (int tile = slot; tile < total_tiles; tile += G) {
       int n, y0, x0;
       decode(tile, n, y0, x0);
-      const int tbuf = ((tile - slot) / G) & 1;                          // patch buffer of this tile
+      const int tbuf = (g >> 1) & 1;                                     // patch buffer of this tile (two chunks per tile)
       const char* patch = smem + patch_base + tbuf * C::PATCH_BYTES;
       const int zero_off = PATCH_ELEMS * 4;
 #pragma unroll
@@ -490,6 +518,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     const float up_sh = Hs > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
     const float up_sw = Ws > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f;
 
+    // Tile-invariant part of a lane's halo offsets: a tile whose halo lies inside the image (most of them) only adds
+    // its origin; the per-pixel bounds tests are left to the tiles on the image border.
+    int lane_off0[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
+      const bool valid = hyx[it] >= 0 && my_k8 < a.C0;
+      lane_off0[it] = valid ? (my_k8 >> 4) * (int)plane_bytes0 + ((((hy - 1) * W + (hx - 1)) * P + my_pl) * cb0 + (my_k8 & 15)) * 2 : (int)OOB;
+    }
     unsigned voff0[ITERS];
     __amdgpu_buffer_rsrc_t rsrc0, rsrc1;
     constexpr int LSR = UPF ? C::LS_ITERS : 1, UPR = UPF ? C::UP_ROUNDS : 1;
@@ -523,13 +560,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     };
 
     auto setup_tile = [&](int n, int y0, int x0) {
+      if (y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W) {          // halo rows y0-1 .. y0+TH, columns x0-1 .. x0+TW
+        const unsigned origin = (unsigned)((y0 * W + x0) * P * cb0 * 2);
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const unsigned pix = (unsigned)((gy * W + gx) * P + my_pl);
-        voff0[it] = (ok && my_k8 < a.C0) ? (unsigned)(my_k8 >> 4) * plane_bytes0 + (pix * cb0 + (my_k8 & 15)) * 2u : OOB;
+        for (int it = 0; it < ITERS; ++it) voff0[it] = origin + (unsigned)lane_off0[it];   // OOB + origin stays out of range
+      } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int hy = hyx[it] >> 8, hx = hyx[it] & 255;
+          const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+          const bool ok = hyx[it] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          const unsigned pix = (unsigned)((gy * W + gx) * P + my_pl);
+          voff0[it] = (ok && my_k8 < a.C0) ? (unsigned)(my_k8 >> 4) * plane_bytes0 + (pix * cb0 + (my_k8 & 15)) * 2u : OOB;
+        }
       }
       rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)n * H * W * P * a.C0), 0, (int)img_bytes0, 0x00020000);
       if (UPF) {
@@ -688,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
     };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
+    const bool slabs_stay = a.nchunks == 2 && a.nct == 1;
 #ifdef UNETPP_WS_DBG
     st_t = __builtin_readcyclecounter();
 #endif
@@ -711,9 +755,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
               blds16(rsrc0, voff0[it], c * (int)plane_bytes0, lds_base + buf + piece * 1024);
           }
         }
+        // A layer of two chunks and one channel tile keeps its weights: chunk c of every tile lands in stage c, so the
+        // slabs this workgroup loaded for its first tile are still there (a third of the bytes and DMA pieces saved).
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 8))
 #endif
+        if (!(slabs_stay && g >= 2))
 #pragma unroll
         for (int it = 0; it < C::SLAB_ITERS; ++it) {
           const int piece = pw + it * C::NPROD;
