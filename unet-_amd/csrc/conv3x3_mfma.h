@@ -202,11 +202,12 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 __device__ __forceinline__ void split_pack2(float v0, float v1, unsigned& wh, unsigned& wl) {
   half2v ph = {(half_t)v0, (half_t)v1};                 // v_cvt_pk_f16_f32
   wh = __builtin_bit_cast(unsigned, ph);
-  float l0, l1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(wh), "v"(v0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(wh), "v"(v1));
-  half2v pl = {(half_t)l0, (half_t)l1};
-  wl = __builtin_bit_cast(unsigned, pl);
+  // lo = fp16(v - hi): one mixed-precision FMA per value reads hi out of the packed word, subtracts in fp32 and writes
+  // the rounded result straight into its half of the lo word (no separate conversion / pack)
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(wh), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(wh), "v"(v1));
+  wl = l;
 }
 
 template <int P>

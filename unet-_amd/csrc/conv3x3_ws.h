@@ -364,9 +364,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   }
   __syncthreads();                                       // sb_lds / head_lds (C0F: slabs, first patch) visible
 
+#ifdef UNETPP_WS_DBG
+#define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; }
+#define WS_STAMP_IN(i) if (a.dbg & 32768) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WS_STAMP(i) __builtin_amdgcn_sched_barrier(0); }
+#else
+#define WS_STAMP(i) {}
+#define WS_STAMP_IN(i) {}
+#endif
   if (C0F && wave >= C::NCONS) {
     // =============================================================== producers, fused first block
     const int pw = wave - C::NCONS;
+#ifdef UNETPP_WS_DBG
+    // stamps: [0] patch prefetch issue, [1] conv1 groups, [2] patch store, [3] barrier
+    unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_readcyclecounter();
+#endif
 #ifndef UNETPP_C0_PRIO
 #define UNETPP_C0_PRIO 1
 #endif
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           decode(ntile, n2, y2, x2);
           patch_fetch(n2, y2, x2, pv);
         }
+        WS_STAMP(0)
         char* himg = smem + c * C::BUF_BYTES;
         float vmax = 0.f;
         // groups in batches of GB: all operand reads of a batch first, then its MFMAs, then its epilogues, so that the
@@ -478,10 +491,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           }
         }
         if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
+        WS_STAMP(1)
         if (have_next) patch_store(tbuf ^ 1, pv);
+        WS_STAMP(2)
         lds_barrier();                                    // chunk g published; the consumers have left the other image
+        WS_STAMP(3)
       }
     }
+#ifdef UNETPP_WS_DBG
+    if (a.stamps && pw == 0 && lane == 0)
+#pragma unroll
+      for (int i = 0; i < 11; ++i) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + i] = st_sum[i];
+#endif
     return;
   }
 
@@ -621,16 +642,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     };
 
 #ifdef UNETPP_WS_DBG
-    // stamps: [0] skip-chunk issue, [1] skip-chunk wait, [2] skip-chunk barrier, [3] up-chunk issue, [4] interpolation,
+    // stamps (macros near the top of the kernel): [0] skip-chunk issue, [1] skip-chunk wait, [2] skip-chunk barrier, [3] up-chunk issue, [4] interpolation,
     // [5] up-chunk wait, [6] up-chunk barrier, [7] tile setup; with dbg bit 32768 the interpolation is cut into
     // [8] corner reads issued and landed, [9] arithmetic, [10] stores issued and retired (instead of [4])
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; }
-#define WS_STAMP_IN(i) if (a.dbg & 32768) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WS_STAMP(i) __builtin_amdgcn_sched_barrier(0); }
     unsigned long long st_t = 0;
-#else
-#define WS_STAMP(i) {}
-#define WS_STAMP_IN(i) {}
 #endif
     // all interpolation items of this lane for up-chunk c: staging buffer (c & 1) -> halo image.  Straight-line code
     // for all rounds (the LDS reads of every round are issued before the first value is needed; a lane without an
