@@ -333,11 +333,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       range_flag(a.status, beyond, nan);
     }
   };
-  auto patch_store = [&](int buf, const float (&val)[PATCH_LOADS]) {      // LDS image [row][col][RGB] float32
-    float* pd = (float*)(smem + patch_base + buf * C::PATCH_BYTES);
+  // LDS image [row][col][RGB], one word per sample: fp16 hi in the low half, fp16 lo (= sample - hi) in the high half --
+  // split once per tile here instead of once per use (every sample is an operand of up to nine pixels, in two chunks)
+  auto patch_store = [&](int buf, const float (&val)[PATCH_LOADS]) {
+    unsigned* pd = (unsigned*)(smem + patch_base + buf * C::PATCH_BYTES);
 #pragma unroll
     for (int i = 0; i < PATCH_LOADS; ++i)
-      if (pe_idx[i] >= 0) pd[pe_idx[i]] = val[i];
+      if (pe_idx[i] >= 0) {
+        unsigned wh, wl;
+        split_pack2(val[i], 0.f, wh, wl);
+        pd[pe_idx[i]] = (wh & 0xffffu) | (wl << 16);
+      }
   };
   if (C0F && wave >= C::NCONS) {
     // conv2's two weight slabs: resident for the whole launch (buffer c holds chunk c)
@@ -438,58 +444,72 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #endif
         constexpr int GB = UNETPP_C0_GB;
         static_assert(C::C0_ITERS % GB == 0, "group batches");
-        // this lane's pixel of group pw + 4 it: hp = 16 (pw + 4 it) + pxl, advanced by 64 halo pixels per group
-        int hy = (pw * 16 + pxl) / HALO_W, hx = (pw * 16 + pxl) - hy * HALO_W;
+        // this lane's pixel of group pw + 4 it: hp = 16 (pw + 4 it) + pxl, advanced by 64 halo pixels per group; in the
+        // halo image that is piece pw + 4 it, slot pxl: a lane-constant offset plus 4 KB per group
+        const int dst_lane = ((kq >> 1) * PPP + pxl) * 16 + (kq & 1) * 8;
+        auto groups = [&](auto interior_tag) {
+          constexpr bool INTERIOR = decltype(interior_tag)::value;      // the whole halo lies inside the image
+          int hy = (pw * 16 + pxl) / HALO_W, hx = (pw * 16 + pxl) - hy * HALO_W;
 #pragma nounroll                                        // (unrolled, the per-group index math is hoisted out of the tile loop: spills)
-        for (int b0 = 0; b0 < C::C0_ITERS; b0 += GB) {
-          float bv[GB][8];
-          int ghy[GB], ghx[GB];
+          for (int b0 = 0; b0 < C::C0_ITERS; b0 += GB) {
+            unsigned bw[GB][8];                           // packed (hi, lo) halves of the 8 operand values, see patch_store
+            int ghy[GB], ghx[GB];
 #pragma unroll
-          for (int k = 0; k < GB; ++k) {
-            ghy[k] = hy; ghx[k] = hx;
-            const int hyc = min(hy, TH + 1);                  // the last group runs past the halo: any valid address
-            const int pix_off = (hyc * C::PATCH_W + hx) * 12;
+            for (int k = 0; k < GB; ++k) {
+              ghy[k] = hy; ghx[k] = hx;
+              const int hyc = min(hy, TH + 1);                  // the last group runs past the halo: any valid address
+              const int pix_off = (hyc * C::PATCH_W + hx) * 12;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bv[k][i] = *(const float*)(patch + (koff[i] >= 0 ? pix_off + koff[i] : zero_off + 4 * i));
-            hy += 1; hx += 64 - HALO_W;                        // + 64 pixels = one row and 30 columns
-            if (hx >= HALO_W) { hx -= HALO_W; hy += 1; }
-          }
-          f32x4 acc[GB];
-#pragma unroll
-          for (int k = 0; k < GB; ++k) {
-            unsigned bh[4], bl[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) split_pack2(bv[k][2 * i], bv[k][2 * i + 1], bh[i], bl[i]);
-            const half8 xh = __builtin_bit_cast(half8, (u32x4){bh[0], bh[1], bh[2], bh[3]});
-            const half8 xl = __builtin_bit_cast(half8, (u32x4){bl[0], bl[1], bl[2], bl[3]});
-            acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xl, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_l[c], xh, acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xh, acc[k], 0, 0, 0);
-          }
-#pragma unroll
-          for (int k = 0; k < GB; ++k) {
-            // lane: pixel pxl of the group, channels 16 c + 4 kq + r.  Halo pixels outside the image are conv2's zero padding.
-            const bool valid = ghy[k] < TH + 2;
-            const int hp = ghy[k] * HALO_W + ghx[k];
-            const int gy = y0 - 1 + ghy[k], gx = x0 - 1 + ghx[k];
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = inside ? fmaxf(acc[k][r] * sc1[c][r] + bi1[c][r], 0.f) : 0.f;
-              vmax = fmaxf(vmax, v[r]);
+              for (int i = 0; i < 8; ++i) bw[k][i] = *(const unsigned*)(patch + (koff[i] >= 0 ? pix_off + koff[i] : zero_off + 4 * i));
+              hy += 1; hx += 64 - HALO_W;                        // + 64 pixels = one row and 30 columns
+              if (hx >= HALO_W) { hx -= HALO_W; hy += 1; }
             }
-            unsigned oh0, oh1, ol0, ol1;
-            split_pack2(fminf(v[0], F16_MAX), fminf(v[1], F16_MAX), oh0, ol0);
-            split_pack2(fminf(v[2], F16_MAX), fminf(v[3], F16_MAX), oh1, ol1);
-            if (valid) {
-              char* dst = himg + (hp / PPP) * 1024 + ((kq >> 1) * PPP + hp % PPP) * 16 + (kq & 1) * 8;
-              *(u32x2*)dst = (u32x2){oh0, oh1};
-              *(u32x2*)(dst + KG * PPP * 16) = (u32x2){ol0, ol1};
+            f32x4 acc[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+              unsigned bh[4], bl[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {               // hi halves / lo halves of two neighbouring values into one word each
+                bh[i] = __builtin_amdgcn_perm(bw[k][2 * i + 1], bw[k][2 * i], 0x05040100u);
+                bl[i] = __builtin_amdgcn_perm(bw[k][2 * i + 1], bw[k][2 * i], 0x07060302u);
+              }
+              const half8 xh = __builtin_bit_cast(half8, (u32x4){bh[0], bh[1], bh[2], bh[3]});
+              const half8 xl = __builtin_bit_cast(half8, (u32x4){bl[0], bl[1], bl[2], bl[3]});
+              acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xl, acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_l[c], xh, acc[k], 0, 0, 0);
+              acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_h[c], xh, acc[k], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+              // lane: pixel pxl of the group, channels 16 c + 4 kq + r.  Halo pixels outside the image are conv2's zero padding.
+              const int gi = pw + (b0 + k) * C::NPROD;           // group index = piece of the halo image
+              const bool valid = gi * 16 + pxl < C::NHALO;
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[k][r] * sc1[c][r] + bi1[c][r];
+              vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);          // v_max3_f32; before the clamp
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], 0.f, F16_MAX);        // ReLU and the fp16 range in one
+              if (!INTERIOR) {
+                const int gy = y0 - 1 + ghy[k], gx = x0 - 1 + ghx[k];
+                const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = inside ? v[r] : 0.f;
+              }
+              unsigned oh0, oh1, ol0, ol1;
+              split_pack2(v[0], v[1], oh0, ol0);
+              split_pack2(v[2], v[3], oh1, ol1);
+              if (valid) {
+                char* dst = himg + gi * 1024 + dst_lane;
+                *(u32x2*)dst = (u32x2){oh0, oh1};
+                *(u32x2*)(dst + KG * PPP * 16) = (u32x2){ol0, ol1};
+              }
             }
           }
-        }
+        };
+        if (y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W) groups(std::true_type());
+        else groups(std::false_type());
         if (__builtin_amdgcn_ballot_w64(vmax > F16_MAX)) range_flag(a.status, vmax > F16_MAX, false);
         WS_STAMP(1)
         if (have_next) patch_store(tbuf ^ 1, pv);
