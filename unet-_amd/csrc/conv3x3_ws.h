@@ -902,6 +902,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.h[m + dy], acc[m][j], 0, 0, 0);
       }
   };
+  // the first tap of a tile's first chunk starts every accumulator from the constant 0 (an inline operand of the
+  // MFMA): a tile without start values never writes zeros into its 64 accumulator registers
+  auto run_mfma_first = [&](const AFrag& fa, const BFrag& fb) {
+    const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        if (P == 2) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.l[m], zero, 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.l[j], fa.h[m], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.h[m], acc[m][j], 0, 0, 0);
+        } else {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb.h[j], fa.h[m], zero, 0, 0, 0);
+        }
+      }
+  };
 
   int g = 0;
 #ifdef UNETPP_WS_DBG
@@ -928,11 +945,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = z4[i];
           }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
         }
       }
+    const bool from_zero = a.zinit == nullptr;
     WS_STAMP(3)
     for (int c = 0; c < a.nchunks; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
@@ -966,7 +981,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
           if (!(a.dbg & 4))
 #endif
-          run_mfma(fa, fb, dy);
+          {
+            if (step == 0 && c == 0 && from_zero) run_mfma_first(fa, fb);
+            else run_mfma(fa, fb, dy);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
