@@ -68,6 +68,28 @@ __global__ __launch_bounds__(256, 1) void kreg(const char* src, size_t bytes, in
   }
   if (lane == 0) { out[(blockIdx.x * 4 + wave) * 2] = issue; out[(blockIdx.x * 4 + wave) * 2 + 1] = wait; }
 }
+// how the L2-resident rate scales with the number of loader waves per CU (1 .. 8 of a 512-thread workgroup)
+__global__ __launch_bounds__(512, 1) void kwaves(const char* src, size_t bytes, int nwaves, int iters, unsigned long long* out, int soff) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0x7fffffff, 0x00020000);
+  unsigned long long total = 0;
+  for (int it = 0; it < iters; ++it) {
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (wave < nwaves) {
+#pragma unroll
+      for (int p = 0; p < 10; ++p) {
+        const size_t off = ((size_t)blockIdx.x * 131072 + (size_t)((wave * 10 + p) % 96) * 1024) % (bytes - 131072);
+        blds16(rs, (unsigned)off + lane * 16, soff, lds_base + (wave * 10 + p) * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    total += __builtin_readcyclecounter() - t0;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = total;
+}
 int main() {
   const size_t bytes = 1ull << 30;
   char* src; unsigned long long* out;
@@ -93,6 +115,15 @@ int main() {
     is /= 1024.0 * iters; wt /= 1024.0 * iters;
     printf("via registers, %-28s: issue %.0f cycles (%.0f per piece), then ds_write + wait %.0f; %.1f KB per us and CU at 2.0 GHz\n", names[mode], is, is / 10, wt,
            40.0 / ((is + wt) / 2000.0));
+  }
+  for (int nw = 1; nw <= 8; nw *= 2) {
+    for (int rep = 0; rep < 2; ++rep) kwaves<<<256, 512, 160 * 1024 - 1024>>>(src, bytes, nw, iters, out, 0);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256);
+    hipMemcpy(h.data(), out, 256 * 8, hipMemcpyDeviceToHost);
+    double t = 0; for (auto v : h) t += v;
+    t /= 256.0 * iters;
+    printf("L2-resident LDS-DMA, %d loader waves per CU: %.0f cycles per batch of %d KB -> %.1f KB per us and CU at 2.0 GHz\n", nw, t, nw * 10, nw * 10 / (t / 2000.0));
   }
   return 0;
 }
