@@ -1,5 +1,6 @@
-// conv3x3_ws.h — the 3x3 convolution of conv3x3_mfma.h for the narrow full-resolution layers (Cout = 32: conv0_0.*,
-// conv0_4.*, reference src/models/unetpp.py:68,82,104,116), with the work of a workgroup SPLIT BY ROLE:
+// conv3x3_ws.h — the 3x3 convolution of conv3x3_mfma.h (every ConvBlock conv of the exact-mode UNet++, reference
+// src/models/unetpp.py:13-26,68-82,104-116; first built for the narrow Cout = 32 layers), with the work of a workgroup
+// SPLIT BY ROLE:
 //
 //   waves 0-3  consumers   fragment reads + MFMAs (one wave per SIMD, 4 rows x 32 pixels x 32 channels each), epilogue
 //   waves 4-7  producers   everything that fills LDS: halo / weight-slab LDS-DMA, and (UPF) the bilinear x2 upsample
@@ -25,6 +26,12 @@
 // for all sizes up to 4096 in tests/test_host_logic.py), so one producer lane takes a block x 4 channels: 8 ds_read_b64,
 // the four corner values c = hi + lo (exact in fp32), two x-interpolations per row, four y-interpolations, the
 // hi/lo re-split, 8 ds_write_b64.
+//
+// Further: HANDOFF -- layers whose producers only move data get half of every tile's epilogue from
+// the consumers through LDS; a layer of two chunks and one channel tile keeps its weight slabs in LDS; the first tap
+// of a tile starts from the MFMA's zero operand; C0F -- the producers compute conv0_0.conv1 themselves (below).
+// Built with -fno-slp-vectorize (unet-_amd/_lib.py): packed fp32 VALU instructions are 5-10x slower beside the
+// consumers' MFMA stream.  Measurement builds (-DUNETPP_WS_DBG): phase ablations and in-kernel phase stamps.
 #pragma once
 #include "conv3x3_mfma.h"
 

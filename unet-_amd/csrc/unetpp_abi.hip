@@ -140,7 +140,7 @@ struct unetpp_engine {
   int c0f_conv1 = -1;             // index of conv0_0.conv1 in `convs` when the first block is fused, else -1
   int ws_max_cout = 512;          // largest Cout the 8-row wave-specialised tiles are used for (UNETPP_WS_MAX_COUT; measured: every layer gains 1-8 %)
   bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
-  bool use_ws = true;             // wave-specialised kernel for the Cout = 32 layers (UNETPP_NO_WS=1: the lock-step one)
+  bool use_ws = true;             // exact-mode convs in the wave-specialised kernel (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
 };
 
@@ -245,7 +245,7 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
   return hipGetLastError();
 }
 
-// wave-specialised kernel for the Cout = 32 layers (conv3x3_ws.h): 16-row tiles, one persistent workgroup per CU
+// wave-specialised kernel (conv3x3_ws.h): 16-row tiles (Cout = 32) or 8-row tiles (Cout % 64 == 0), one persistent workgroup per CU
 template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   using C = WsCfg<P, UPF, C0F, NW, MW>;
@@ -897,7 +897,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           bytes += px * ((lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tpe ? 1 : 0));
           head_done = true;
         }
-        // exact mode, Cout = 32, single source (or skip + fused upsample): the wave-specialised kernel
+        // exact mode, Cout = 32 or a multiple of 64, single source (or skip + fused upsample): the wave-specialised kernel
         const bool ws = e->use_ws && P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
