@@ -19,6 +19,19 @@ __device__ __forceinline__ void valu_block(float (&x)[16], float w0, float w1) {
       if (KIND == 2) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
       if (KIND == 3) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
       if (KIND == 4) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x[i]) : "v"(w0));
+      if (KIND == 5) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[i]), "+v"(x[(i + 1) & 15]));
+      if (KIND == 6) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(x[i]) : "v"(x[(i + 1) & 15]));
+      if (KIND == 7) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
+      if (KIND == 8) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(w1), "v"(w0));
+      if (KIND == 9) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]), "v"(w0));
+      if (KIND == 10) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
+      if (KIND == 11) asm volatile("v_exp_f32 %0, %1" : "=v"(x[i]) : "v"(x[(i + 1) & 15]));
+      if (KIND == 12) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]) : "vcc");
+      if (KIND == 13) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(x[i]) : "v"(x[(i + 1) & 15]));
+      if (KIND == 14) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
+      if (KIND == 15) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
+      if (KIND == 16) asm volatile("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x[i]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]));
+      if (KIND == 17) asm volatile("v_readlane_b32 s20, %1, 3\n\tv_mov_b32 %0, s20" : "=v"(x[i]) : "v"(x[(i + 1) & 15]) : "s20");
     }
 }
 
@@ -82,6 +95,12 @@ int main() {
     run<2>("v_fma_mix_f32", mode);
     run<3>("v_cvt_pk_f16_f32", mode);
     run<4>("v_add_u32", mode);
+    if (mode == 0 || mode == 3) {
+      run<5>("v_permlane32_swap", mode); run<6>("v_mov_b32 dpp", mode); run<7>("v_max3_f32", mode); run<8>("v_med3_f32", mode);
+      run<9>("v_perm_b32", mode); run<10>("v_fma_mixlo_f16", mode); run<11>("v_exp_f32", mode); run<12>("v_cndmask_b32", mode);
+      run<13>("v_cvt_f32_f16", mode); run<14>("v_pk_mul_f16", mode); run<15>("v_mul_lo_u32", mode); run<16>("v_lshl_add_u32", mode);
+      run<17>("v_readlane+v_mov", mode);
+    }
   }
   return 0;
 }
