@@ -42,9 +42,14 @@ __global__ void weight_scale_kernel(const float* __restrict__ w, int per_co, con
   }
 }
 
-// canonical OIHW fp32 -> [ct][chunk][P][tap][KG][BN][8] fp16 (plane 0 = hi, plane 1 = lo)
+// canonical OIHW fp32 -> [ct][chunk][P][tap][KG][BN][8] fp16 (plane 0 = hi, plane 1 = lo).
+// rows8 (layers of the wave-specialised kernel): inside every 32-row block of the MFMA's A operand, row
+// (r & 3) + 8 (r >> 2) + 4 h carries output channel 16 (r >> 3) + 8 h + (r & 7) -- the accumulator layout of
+// v_mfma_f32_32x32x16 then leaves a lane (h = lane >> 5) with channels 8 h .. 8 h + 7 of the tile's first 16-channel
+// record in registers 0..7 and the same eight of its second record in registers 8..15: the epilogue stores 16-byte
+// pieces without exchanging words between the two half-waves (8 v_permlane32_swap per row otherwise, 12-16 cycles each).
 __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __restrict__ mult, int Cin, int Cout,
-                                   int P, int KC, int BN, int nchunks, half_t* __restrict__ out, long long units) {
+                                   int P, int KC, int BN, int nchunks, half_t* __restrict__ out, long long units, int rows8) {
   long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   const int KG = KC / 8;
@@ -56,6 +61,10 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
   int c = t % nchunks; t /= nchunks;
   int ct = (int)t;
   int co = ct * BN + n;
+  if (rows8) {
+    const int nb = n & 31, h = (nb >> 2) & 1, r = (nb & 3) + 4 * (nb >> 3);
+    co = ct * BN + (n & ~31) + 16 * (r >> 3) + 8 * h + (r & 7);
+  }
   half8 r;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

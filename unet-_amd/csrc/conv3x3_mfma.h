@@ -247,6 +247,30 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
   }
 }
 
+// The same for accumulators of weights packed with rows8 (weight_pack_kernel): registers 0..7 are channels 8 h .. 8 h + 7
+// of the tile's first record, registers 8..15 the same eight of the second -- the stores of pack_store_octets without
+// its exchange between the half-waves.
+template <int P>
+__device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    unsigned wh[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (P == 2) {
+        split_pack2(v[8 * pi + 2 * i], v[8 * pi + 2 * i + 1], wh[i], wl[i]);
+      } else {
+        half2v ph = {(half_t)v[8 * pi + 2 * i], (half_t)v[8 * pi + 2 * i + 1]};
+        wh[i] = __builtin_bit_cast(unsigned, ph);
+      }
+    }
+    if (ok) {
+      *(u32x4*)(dst + pi * blk_stride + 8 * h) = (u32x4){wh[0], wh[1], wh[2], wh[3]};
+      if (P == 2) *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = (u32x4){wl[0], wl[1], wl[2], wl[3]};
+    }
+  }
+}
+
 constexpr int HEAD_MAX_CLASSES = 16;
 constexpr int HEAD_FUSED_MAX_CLASSES = 8;   // the fused head keeps all logits in registers
 

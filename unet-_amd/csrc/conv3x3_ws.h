@@ -80,7 +80,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Epilogue of ROWS image rows (acc[m] = row gy0 + m) x 32 pixels x 32 channels [cbase, cbase + 32) held in MFMA
-// accumulators (pixel on the lane, channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) in register r): scale, bias, ReLU,
+// accumulators (pixel on the lane; the weights are packed with rows8, so register r holds channel
+// 16 * (r >> 3) + 8 * (lane >> 5) + (r & 7): eight consecutive channels of each of the tile's two records): scale, bias, ReLU,
 // then either the fp16 hi/lo store (+ the fused 2x2 max-pool of rows (0,1), (2,3), ...) or the fused 1x1 head with
 // softmax / argmax / class rules.  Same arithmetic, statement for statement, as the epilogue of conv3x3_bias_relu_kernel.
 template <int P, int ROWS, bool POOL, bool HEAD>
@@ -94,7 +95,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
   float vmax = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int co = cbase + 16 * (r >> 3) + 8 * h + (r & 7);
     const float2 sb = sb_lds[co];
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
@@ -116,7 +117,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = gy < H && gx < W;
       const size_t blk = (size_t)H * W * P * 16;
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)gy * W + gx) * P * 16;
-      pack_store_octets<P>(v[m], dst, blk, ok, h);
+      pack_store_rows8<P>(v[m], dst, blk, ok, h);
     }
   } else {
     // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: a lane holds 16 of a pixel's 32 channels, lane ^ 32 the
@@ -135,7 +136,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
           float wq[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 w4 = *(const float4*)(head_lds + c * 32 + 8 * q + 4 * h);
+            const float4 w4 = *(const float4*)(head_lds + c * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1));
             wq[4 * q] = w4.x; wq[4 * q + 1] = w4.y; wq[4 * q + 2] = w4.z; wq[4 * q + 3] = w4.w;
           }
           const float bc = head_lds[a.head_C * 32 + c];
@@ -202,7 +203,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
       const size_t blk = (size_t)Hp * Wp * P * 16;
       half_t* dst = a.pool_out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)py * Wp + px) * P * 16;
-      pack_store_octets<P>(pv, dst, blk, ok, h);
+      pack_store_rows8<P>(pv, dst, blk, ok, h);
     }
   }
 }
@@ -944,11 +945,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           typedef __attribute__((ext_vector_type(4))) float f32x4;
           const int gy = y0 + cw * MW + m, gx = x0 + (lane & 31);
           const bool in = gy < H && gx < W;
-          const float* zp = a.zinit + (((size_t)n * (a.Cout >> 5) + ((ct * BN + j * 32) >> 5)) * ((size_t)H * W) + (size_t)gy * W + gx) * 32 + 4 * (lane >> 5);
+          const float* zp = a.zinit + (((size_t)n * (a.Cout >> 5) + ((ct * BN + j * 32) >> 5)) * ((size_t)H * W) + (size_t)gy * W + gx) * 32 + 8 * (lane >> 5);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            if (in) z4 = *(const f32x4*)(zp + 8 * q);
+            if (in) z4 = *(const f32x4*)(zp + 16 * (q >> 1) + 4 * (q & 1));     // registers 4 q .. 4 q + 3 (rows8 channel order)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = z4[i];
           }

@@ -691,6 +691,11 @@ void unetpp_destroy(unetpp_engine* e) {
 
 size_t unetpp_workspace_bytes(const unetpp_engine* e) { return e ? e->arena_bytes : 0; }
 
+// which conv layers run in the wave-specialised kernel (a property of the engine and the layer, not of a call)
+static bool layer_uses_ws(const unetpp_engine* e, const ConvLayer& L) {
+  return e->use_ws && e->P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
+}
+
 static int repack(unetpp_engine* e, hipStream_t s) {
   const int P = e->P;
   for (auto& L : e->convs) {
@@ -699,7 +704,7 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     const int BN = 32 * L.NW;
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
-                       L.cout, P, L.KC, BN, L.nchunks, L.wpk, units);
+                       L.cout, P, L.KC, BN, L.nchunks, L.wpk, units, layer_uses_ws(e, L) ? 1 : 0);
   }
   for (auto& L : e->convs) {
     if (L.zt < 0) continue;
@@ -898,7 +903,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           head_done = true;
         }
         // exact mode, Cout = 32 or a multiple of 64, single source (or skip + fused upsample): the wave-specialised kernel
-        const bool ws = e->use_ws && P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
+        const bool ws = layer_uses_ws(e, L);
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
         auto tf = [](bool v) { return v ? "true" : "false"; };
