@@ -30,6 +30,8 @@ python3 scripts/pmc_layers.py $FETCH $WRITE > profiles/${TAG}_pmc_per_layer.txt
 python3 scripts/pmc_mfma.py $MFMA $STATS > profiles/${TAG}_pmc_mfma_busy.txt
 cp $OUT/bench.json profiles/${TAG}_bench.json
 cp $OUT/bench_under_rocprof.json profiles/${TAG}_bench_under_rocprof.json
+# the un-profiled bench line once more, now that this build's traffic file exists (so that the line carries `traffic`)
+python3 bench.py --steps 20 --warmup 5 > profiles/${TAG}_bench.json 2> $OUT/bench2.err
 mkdir -p $ROOT/gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* $ROOT/gpurun_out/${TAG}_profiles/
 echo "summaries done" >> $OUT/progress.txt
 tail -3 profiles/${TAG}_pmc_per_layer.txt
