@@ -114,10 +114,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
+def share_torch_hip_runtime() -> None:
+    """Import torch (when it is installed) BEFORE the library is dlopen'ed.  The torch wheel ships its own
+    libamdhip64 / libhsa-runtime64; loaded first, they satisfy this library's DT_NEEDED entries and the process has
+    one HIP runtime.  The other way round the library pulls in /opt/rocm's copies, torch adds its own, and whichever
+    runtime initialises second finds no device ("no HIP device available" from unetpp_create after a torch CUDA call)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load(build_if_missing: bool = True) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    share_torch_hip_runtime()
     if _stale():
         # missing, or built from other sources than the tree holds (the .so is git-ignored but travels to the GPU
         # box): rebuild when a compiler is at hand, otherwise refuse -- never run kernels that do not match the tree
