@@ -67,6 +67,24 @@ def conv(x, w, mode):
         wsl = ws - wsh
         acc = c(xh, wsh) + c(e4(xl * 2.0 ** A), e4(ws * 2.0 ** -A)) + c(e4(x), e4(wsl))
         return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
+    if mode in ("mix", "mixw5", "mix6"):
+        # the EXACT8 scheme as built (csrc/conv3x3_ws.h, P8): activations' 8-bit planes are e5m2 (fp16's exponent range:
+        # no scale, no calibration), weights' are e4m3 with a per-output-channel power-of-two block scale
+        e5 = lambda t: t.clamp(-57344, 57344).to(torch.float32).to(torch.float8_e5m2).to(torch.float64)
+        e4 = lambda t: t.clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        mx = w.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
+        k = 14 - torch.floor(torch.log2(mx)) - 1
+        ws = w * 2.0 ** k
+        wsh = ws.to(torch.float16).to(torch.float64)
+        wsl = (ws - wsh).to(torch.float16).to(torch.float64)
+        def qw(t):
+            if mode == "mixw5":
+                return e5(t)
+            m = t.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
+            s = 2.0 ** (8 - torch.floor(torch.log2(m)) - 1)      # max |t s| in [128, 256)
+            return e4(t * s) / s
+        acc = c(xh, wsh) + c(e5(xl), qw(wsh)) + c(e5(x), qw(wsl))
+        return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
     if mode == "bf8":
         return c(xh, wh) + c(q_e4m3(xl, 2), q_e4m3(w, 2)) + c(q_e4m3(x, 2), q_e4m3(wl, 2))
     raise ValueError(mode)
