@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
 ]
 
 STATUS_OVERFLOW, STATUS_NAN = 1, 2
-PREC_EXACT, PREC_FAST = 0, 1
+PREC_EXACT, PREC_FAST, PREC_EXACT8 = 0, 1, 2
+PRECISIONS = {"exact": PREC_EXACT, "fast": PREC_FAST, "exact8": PREC_EXACT8}
 ARCH_NESTED, ARCH_SIMPLE = 0, 1
 IN_F32_NCHW, IN_U8_NHWC_BGR = 0, 1
 

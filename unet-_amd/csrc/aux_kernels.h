@@ -77,6 +77,63 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
   *(half8*)(out + u * 8) = r;
 }
 
+// EXACT8 slabs of the wave-specialised kernel (conv3x3_ws.h, X8): per (channel tile, chunk of 16 input channels)
+//   main   [tap 9][k-group 2][BN][8 halves]         fp16(w 2^k), the hi plane of weight_pack_kernel (rows8 order)
+//   cross  [pair 5][tap of the pair 2][h 2][BN][16 bytes]   e4m3 bytes; lane (n, h) of the scaled MFMA's first operand holds,
+//          per tap, [wh8 x 4 | wl8 x 4 | wh8 x 4 | wl8 x 4] for input channels 8 h + 0..3 and 8 h + 4..7 -- the order of the
+//          activations' [lo8 x 4 | x8 x 4 | ...] bytes (conv3x3_mfma.h) -- with
+//             wh8 = e4m3(2^-6 ws)   (ws = w 2^k, max |ws| in [2^13, 2^14): at most 256)
+//             wl8 = e4m3(2^5 (ws - fp16(ws)))   (|ws - fp16(ws)| <= 4: at most 128)
+//          so that with the block scales 2^6 (weights) and 2^-8 (activations: lo8 = 2^8 lo, x8 = 2^-3 x) the instruction adds
+//          ws * lo + (ws - fp16(ws)) * x.   Pairs (taps as dy * 3 + dx): (0,1) (3,4) (6,7) (2,5) (8,-): the consumers' order.
+__global__ void weight_pack_x8_kernel(const float* __restrict__ w, const float* __restrict__ mult, int Cin, int Cout, int BN, int nchunks,
+                                      char* __restrict__ out, long long units) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int per = 38 * BN;
+  const long long t = u / per;
+  int r = (int)(u - t * per);
+  const int c = (int)(t % nchunks), ct = (int)(t / nchunks);
+  const bool is_main = r < 18 * BN;
+  if (!is_main) r -= 18 * BN;
+  const int n = r % BN;
+  const int nb = n & 31, hh = (nb >> 2) & 1, rr = (nb & 3) + 4 * (nb >> 3);
+  const int co = ct * BN + (n & ~31) + 16 * (rr >> 3) + 8 * hh + (rr & 7);        // rows8, see weight_pack_kernel
+  const float mu = mult[co];
+  if (is_main) {
+    const int kg = (r / BN) & 1, tap = r / (2 * BN);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = c * 16 + kg * 8 + e;
+      o[e] = (half_t)(ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] * mu : 0.f);
+    }
+    *(half8*)(out + u * 16) = o;
+    return;
+  }
+  const int h = (r / BN) & 1, half = (r / (2 * BN)) & 1, pair = r / (4 * BN);
+  const int tap = pair < 3 ? pair * 3 + half : (pair == 3 ? (half ? 5 : 2) : (half ? -1 : 8));
+  unsigned wd[4] = {0u, 0u, 0u, 0u};
+  if (tap >= 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float hi4[4], lo4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = c * 16 + 8 * h + 4 * q + i;
+        const float ws = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] * mu : 0.f;
+        hi4[i] = ws * 0.015625f;
+        lo4[i] = (ws - (float)(half_t)ws) * 32.0f;
+      }
+      int a = 0, b = 0;
+      a = __builtin_amdgcn_cvt_pk_fp8_f32(hi4[0], hi4[1], a, false); a = __builtin_amdgcn_cvt_pk_fp8_f32(hi4[2], hi4[3], a, true);
+      b = __builtin_amdgcn_cvt_pk_fp8_f32(lo4[0], lo4[1], b, false); b = __builtin_amdgcn_cvt_pk_fp8_f32(lo4[2], lo4[3], b, true);
+      wd[2 * q] = (unsigned)a; wd[2 * q + 1] = (unsigned)b;
+    }
+  }
+  *(u32x4*)(out + u * 16) = (u32x4){wd[0], wd[1], wd[2], wd[3]};
+}
+
 // conv0_0.conv1 weights (canonical OIHW fp32 [32][3][3][3]) -> A fragments of v_mfma_f32_16x16x32_f16 for the fused first
 // block (conv3x3_ws.h, C0F): [half c][plane][lane][8]; lane l holds output channel 16 c + (l & 15), operand slots
 // 8 (l >> 4) .. +7 of the K = 32 order [dy 0: (dx,ch) 0..7][dy 1: 0..7][dy 2: 0..7][(dx,ch) = 8 of dy 0, 1, 2][0 x 5].
@@ -455,9 +512,14 @@ __global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, i
   int y = t % H; t /= H;
   int c = t % C; int n = t / C;
   const int CB = C < 16 ? C : 16;                 // channel-blocked source: [N][C/CB][H][W][P][CB]
-  const half_t* p = x + ((((size_t)(n * (C / CB) + c / CB) * H + y) * W + xx) * P) * CB + c % CB;
+  const half_t* p = x + ((((size_t)(n * (C / CB) + c / CB) * H + y) * W + xx) * (P == 3 ? 2 : P)) * CB + c % CB;
   float v = (float)p[0];
   if (P == 2) v += (float)p[CB];
+  if (P == 3) {          // EXACT8 record (CB = 16): hi + 2^-8 lo8, lo8 at byte 32 + 16 (c / 8) + 8 ((c / 4) & 1) + c % 4
+    const int cc = c % 16;
+    const unsigned char b8 = ((const unsigned char*)(p - cc))[32 + 16 * (cc >> 3) + 8 * ((cc >> 2) & 1) + (cc & 3)];
+    v += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)b8, X8_LO_MUL, 0);
+  }
   out[i] = v;
 }
 

@@ -210,6 +210,37 @@ __device__ __forceinline__ void split_pack2(float v0, float v1, unsigned& wh, un
   wl = l;
 }
 
+// ---- EXACT8 (conv3x3_ws.h): an activation is stored as fp16 hi (RNE) plus two e5m2 bytes per value,
+//   lo8 = e5m2(2^8 (v - hi))   the residual, as the 8-bit operand of the  lo * w  cross term
+//   x8  = e5m2(2^-3 v)         the value itself, as the 8-bit operand of the  x * w_lo  cross term
+// (pre-scaled so that neither can overflow or go subnormal where it matters: |v - hi| <= 32, v <= 65504; the scaled
+// MFMA undoes both factors with one block scale).  A 64-byte pixel record of 16 channels is
+//   [hi c0-7][hi c8-15][lo8 c0-3, x8 c0-3, lo8 c4-7, x8 c4-7][the same for c8-15]
+// so that the lanes of every kernel write and read the same 16-byte pieces as in the two-plane fp16 format.
+typedef __attribute__((ext_vector_type(2))) short short2v;
+constexpr float X8_LO_DIV = 0.00390625f, X8_X_DIV = 8.0f;      // v_cvt_scalef32_pk_bf8_f32 divides by its scale operand ...
+constexpr float X8_LO_MUL = 0.00390625f;                       // ... v_cvt_scalef32_f32_bf8 multiplies by it (scripts/microbench/bf8_cvt_probe.hip)
+// the E8M0 block scales of v_mfma_scale_f32_32x32x64_f8f6f4 for (weights e4m3, activations e5m2): 2^6 and 2^-8, see weight_pack_x8_kernel
+constexpr int X8_SCALE_W = 127 + 6, X8_SCALE_A = 127 - 8;
+// four channel values -> two packed fp16 hi words, one word of four lo8 bytes, one word of four x8 bytes
+__device__ __forceinline__ void split_pack4_x8(float v0, float v1, float v2, float v3, unsigned& h0, unsigned& h1, unsigned& l8, unsigned& x8) {
+  half2v p0 = {(half_t)v0, (half_t)v1}, p1 = {(half_t)v2, (half_t)v3};      // v_cvt_pk_f16_f32
+  h0 = __builtin_bit_cast(unsigned, p0); h1 = __builtin_bit_cast(unsigned, p1);
+  float l0, l1, l2, l3;                                                       // v - hi, exact in fp32
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "v"(v0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h0), "v"(v1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h1), "v"(v2));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(h1), "v"(v3));
+  short2v t = {0, 0};
+  t = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t, l0, l1, X8_LO_DIV, false);
+  t = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t, l2, l3, X8_LO_DIV, true);
+  l8 = __builtin_bit_cast(unsigned, t);
+  short2v u = {0, 0};
+  u = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(u, v0, v1, X8_X_DIV, false);
+  u = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(u, v2, v3, X8_X_DIV, true);
+  x8 = __builtin_bit_cast(unsigned, u);
+}
+
 template <int P>
 __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
   unsigned wh[4][2], wl[4][2];
@@ -250,14 +281,19 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
 // The same for accumulators of weights packed with rows8 (weight_pack_kernel): registers 0..7 are channels 8 h .. 8 h + 7
 // of the tile's first record, registers 8..15 the same eight of the second -- the stores of pack_store_octets without
 // its exchange between the half-waves.
-template <int P>
+template <int P, bool X8 = false>
 __device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
 #pragma unroll
   for (int pi = 0; pi < 2; ++pi) {
     unsigned wh[4], wl[4];
+    if (X8) {
+      split_pack4_x8(v[8 * pi], v[8 * pi + 1], v[8 * pi + 2], v[8 * pi + 3], wh[0], wh[1], wl[0], wl[1]);
+      split_pack4_x8(v[8 * pi + 4], v[8 * pi + 5], v[8 * pi + 6], v[8 * pi + 7], wh[2], wh[3], wl[2], wl[3]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (P == 2) {
+      if (X8) {
+      } else if (P == 2) {
         split_pack2(v[8 * pi + 2 * i], v[8 * pi + 2 * i + 1], wh[i], wl[i]);
       } else {
         half2v ph = {(half_t)v[8 * pi + 2 * i], (half_t)v[8 * pi + 2 * i + 1]};

@@ -40,8 +40,10 @@ namespace unetpp {
 // NW x MW = 32-channel blocks x rows per consumer wave: 1 x 4 (Cout = 32, 16-row tiles) or 2 x 2 (Cout = 64, 8-row
 // tiles: the same 108 MFMAs per chunk and wave; the 37 KB weight slab of 64 output channels leaves LDS room for two
 // 8-row halo images only).
-template <int P, bool UPF, bool C0F = false, int NW_ = 1, int MW_ = 4>
+template <int P, bool UPF, bool C0F = false, int NW_ = 1, int MW_ = 4, bool X8_ = false>
 struct WsCfg {
+  static constexpr bool X8 = X8_;
+  static_assert(!X8 || P == 2, "EXACT8 keeps the 64-byte pixel records of the two-plane format");
   static constexpr int NT = 512, NCONS = 4, NPROD = 4, MW = MW_, NW = NW_;
   static constexpr int TH = NCONS * MW, TW = 32, HALO_W = TW + 2, NHALO = (TH + 2) * HALO_W;
   static constexpr int KC = 16, KG = 2, BN = 32 * NW;
@@ -49,7 +51,10 @@ struct WsCfg {
   static constexpr int U = P * KG, PPP = 64 / U;
   static constexpr int HALO_PIECES = (NHALO + PPP - 1) / PPP, HALO_BYTES = HALO_PIECES * 1024;
   static constexpr int HALO_ITERS = (HALO_PIECES + NPROD - 1) / NPROD;
-  static constexpr int SLAB_BYTES = P * 9 * KC * BN * 2, SLAB_PIECES = SLAB_BYTES / 1024;
+  // weight slab of one chunk: P planes of [tap][k-group][BN][8 halves]; X8: the hi plane, then the 8-bit weights of the
+  // five tap pairs [pair][tap of the pair][h][BN][16 bytes] (see the EXACT8 notes above the kernel)
+  static constexpr int SLAB_MAIN = 9 * KC * BN * 2;
+  static constexpr int SLAB_BYTES = X8 ? SLAB_MAIN + 5 * 2 * 2 * BN * 16 : P * SLAB_MAIN, SLAB_PIECES = SLAB_BYTES / 1024;
   static constexpr int SLAB_ITERS = (SLAB_PIECES + NPROD - 1) / NPROD;
   static constexpr int BUF_BYTES = HALO_BYTES + SLAB_BYTES;
   static constexpr int LSH = TH / 2 + 2, LSW = TW / 2 + 2, LS_PX = LSH * LSW, LS_REC = P * 32;
@@ -71,6 +76,9 @@ struct WsCfg {
   static_assert(SLAB_BYTES % 1024 == 0 && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int8v __attribute__((ext_vector_type(8)));
+
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's global
 // stores (vmcnt), so a consumer's epilogue stores keep draining while it already multiplies the next tile.
 __device__ __forceinline__ void lds_barrier() {
@@ -84,7 +92,7 @@ __device__ __forceinline__ void lds_barrier() {
 // 16 * (r >> 3) + 8 * (lane >> 5) + (r & 7): eight consecutive channels of each of the tile's two records): scale, bias, ReLU,
 // then either the fp16 hi/lo store (+ the fused 2x2 max-pool of rows (0,1), (2,3), ...) or the fused 1x1 head with
 // softmax / argmax / class rules.  Same arithmetic, statement for statement, as the epilogue of conv3x3_bias_relu_kernel.
-template <int P, int ROWS, bool POOL, bool HEAD>
+template <int P, int ROWS, bool POOL, bool HEAD, bool X8 = false>
 __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&acc)[ROWS], const float2* sb_lds,
                                             const float* head_lds, int n, int gy0, int x0, int cbase, int lane) {
   const int H = a.H, W = a.W;
@@ -117,7 +125,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = gy < H && gx < W;
       const size_t blk = (size_t)H * W * P * 16;
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)gy * W + gx) * P * 16;
-      pack_store_rows8<P>(v[m], dst, blk, ok, h);
+      pack_store_rows8<P, X8>(v[m], dst, blk, ok, h);
     }
   } else {
     // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: a lane holds 16 of a pixel's 32 channels, lane ^ 32 the
@@ -203,7 +211,7 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
       const size_t blk = (size_t)Hp * Wp * P * 16;
       half_t* dst = a.pool_out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)py * Wp + px) * P * 16;
-      pack_store_rows8<P>(pv, dst, blk, ok, h);
+      pack_store_rows8<P, X8>(pv, dst, blk, ok, h);
     }
   }
 }
@@ -218,9 +226,9 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
 // packed conv1 weights (hi/lo split, three MFMAs as everywhere), applies scale/bias/ReLU, writes zeros for halo pixels
 // outside the image (conv2's padding) and stores the hi/lo quads into the halo image.  The two conv2 weight slabs
 // stay in LDS for the whole launch.
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MWP = 4>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MWP = 4, bool X8 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
-  using C = WsCfg<P, UPF, C0F, NW, MWP>;
+  using C = WsCfg<P, UPF, C0F, NW, MWP, X8>;
   static_assert(!C0F || (!UPF && !HEAD && P == 2 && NW == 1), "fused first block: exact mode, no other fusion in the loader");
   static_assert(!HEAD || NW == 1, "the fused head needs all 32 channels of x0_4 in one 32-block");
   constexpr int NT = C::NT, MW = C::MW, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
@@ -506,8 +514,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
                 for (int r = 0; r < 4; ++r) v[r] = inside ? v[r] : 0.f;
               }
               unsigned oh0, oh1, ol0, ol1;
-              split_pack2(v[0], v[1], oh0, ol0);
-              split_pack2(v[2], v[3], oh1, ol1);
+              if (X8) {
+                split_pack4_x8(v[0], v[1], v[2], v[3], oh0, oh1, ol0, ol1);      // {lo8 x 4, x8 x 4} where the lo quad used to go
+              } else {
+                split_pack2(v[0], v[1], oh0, ol0);
+                split_pack2(v[2], v[3], oh1, ol1);
+              }
               if (valid) {
                 char* dst = himg + gi * 1024 + dst_lane;
                 *(u32x2*)dst = (u32x2){oh0, oh1};
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     // records the first read then touches banks [16 rx, 16 rx + 8) in blocks 0..3 and [16 rx + 8, 16 rx + 16) in
     // blocks 4..7 -- all 64 banks once, instead of every bank twice; two separate ds_read_b64 (2 LDS cycles each)
     // also replace the ds_read2_b64 the compiler forms from a fixed +32 offset (8 cycles, banked modulo 32).
-    int rd_swap = (P == 2 && (lane & 16)) ? 32 : 0;
+    int rd_swap = (P == 2 && !X8 && (lane & 16)) ? 32 : 0;      // (X8: hi and the 8-bit planes are not interchangeable)
 #ifdef UNETPP_WS_DBG
     if (a.dbg & 32) rd_swap = 0;
 #endif
@@ -709,7 +721,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             // corner value = hi + lo, exact in fp32; one mixed-precision FMA reads both halves out of the packed words
-            if (P == 2) {
+            if (X8) {
+              // value = hi + 2^-8 lo8: the low-res tensor is what the previous layer stored (hi, lo8); word 0 of the second
+              // read holds the four lo8 bytes of this channel quad
+              const float lo = e == 0 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 0)
+                             : e == 1 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 1)
+                             : e == 2 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 2)
+                                      : __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 3);
+              if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo));
+              else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo));
+            } else if (P == 2) {
               if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
               else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
             } else {
@@ -737,7 +758,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
             for (int kx = 0; kx < 2; ++kx) {
               const int px = 2 * ky + kx;
               unsigned h0, h1, l0 = 0, l1 = 0;
-              if (P == 2) {
+              if (X8) {
+                split_pack4_x8(v[px][0], v[px][1], v[px][2], v[px][3], h0, h1, l0, l1);
+              } else if (P == 2) {
                 split_pack2(v[px][0], v[px][1], h0, l0);
                 split_pack2(v[px][2], v[px][3], h1, l1);
               } else {
@@ -772,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       // the pair is rows (2, 3) of the wave's four rows (MW = 4) or the second 32-channel block of its two rows (MW = 2)
       const int gy0 = hy0 + pw * MW + (MW == 4 ? 2 : 0);
       const int cbase = hct * BN + (MW == 4 ? 0 : 32);
-      ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
+      ws_epilogue<P, 2, POOL, HEAD, X8>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
     };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
     const bool slabs_stay = a.nchunks == 2 && a.nct == 1;
@@ -967,6 +990,118 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
       if (a.dbg & 16) continue;
 #endif
+      if constexpr (X8) {
+        // ---- EXACT8 chunk: 9 main-term steps (fp16 hi planes, one 32-cycle MFMA per product) and 5 cross-term steps (one
+        // 64-cycle K = 64 MFMA per product and tap PAIR).  Order: column 0, column 1, pairs 0-2 (the taps of columns 0 and 1
+        // row by row), column 2, pairs 3-4 (column 2: dy 0 + dy 1, dy 2 + a zero-weight slot).  Each phase reads the
+        // fragments of the next one: h planes of a column during the phase before it, the 8-bit operands of pairs 0-2 during
+        // column 1, those of pairs 3-4 during column 2.
+        constexpr int R = MW + 2;
+        const char* xslab = slab + C::SLAB_MAIN;
+        struct BM { half8 w[NW]; };
+        struct BX { int8v w[NW]; };
+        auto load_h = [&](half8 (&f)[R], int dx, int r0, int r1) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (r >= r0 && r < r1) f[r] = *(const half8*)(halo + a_off[r][dx]);
+        };
+        // 8-bit operand of one pixel row for a tap pair: bytes 0-15 from halo row ra shifted by dxa, bytes 16-31 from (rb, dxb)
+        auto load_x = [&](int dxa, int ra, int dxb, int rb) {
+          const int4v lo = *(const int4v*)(halo + a_off[ra][dxa] + KG * PPP * 16);
+          const int4v hi = *(const int4v*)(halo + a_off[rb][dxb] + KG * PPP * 16);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto load_bm = [&](BM& f, int tap) {
+#pragma unroll
+          for (int j = 0; j < NW; ++j) f.w[j] = *(const half8*)(slab + b_lane_off + (tap * KG * BN + j * 32) * 16);
+        };
+        auto load_bx = [&](BX& f, int pair) {
+#pragma unroll
+          for (int j = 0; j < NW; ++j) {
+            const char* p = xslab + pair * (2 * 2 * BN * 16) + b_lane_off + j * 32 * 16;
+            const int4v lo = *(const int4v*)p, hi = *(const int4v*)(p + 2 * BN * 16);
+            f.w[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        };
+        auto main_step = [&](const BM& b, const half8 (&hf)[R], int dy, bool first) {
+          const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+              acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.w[j], hf[m + dy], first ? zero : acc[m][j], 0, 0, 0);
+        };
+        auto cross_step = [&](const BX& b, const int8v (&x)[R], int r0) {
+#pragma unroll
+          for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+              acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b.w[j], x[m + r0], acc[m][j], 0 /* e4m3 */, 1 /* e5m2 */,
+                                                                         0, X8_SCALE_W, 0, X8_SCALE_A);
+        };
+        half8 h0[R], h1[R];
+        int8v xa[R];
+        BM bm0, bm1;
+        BX bx0, bx1;
+        load_h(h0, 0, 0, R);
+        load_bm(bm0, 0);
+        const bool first = c == 0 && from_zero;
+        // column 0 (taps dy * 3 + 0)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          BM& b = (dy & 1) ? bm1 : bm0;
+          BM& bn = (dy & 1) ? bm0 : bm1;
+          load_bm(bn, dy < 2 ? (dy + 1) * 3 : 1);
+          load_h(h1, 1, 2 * dy, 2 * dy + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (dy == 0 && first) main_step(b, h0, 0, true); else main_step(b, h0, dy, false);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // column 1 (steps 3..5); meanwhile the operands of pairs 0-2: row r of column 0 | row r of column 1
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          BM& b = ((3 + dy) & 1) ? bm1 : bm0;
+          BM& bn = ((3 + dy) & 1) ? bm0 : bm1;
+          if (dy < 2) load_bm(bn, (dy + 1) * 3 + 1); else load_bx(bx0, 0);
+#pragma unroll
+          for (int r = 2 * dy; r < 2 * dy + 2 && r < R; ++r) xa[r] = load_x(0, r, 1, r);
+          __builtin_amdgcn_sched_barrier(0);
+          main_step(b, h1, dy, false);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // pairs 0-2: taps (dy, 0) + (dy, 1); meanwhile the h planes of column 2
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+          BX& b = (pr & 1) ? bx1 : bx0;
+          BX& bn = (pr & 1) ? bx0 : bx1;
+          if (pr < 2) load_bx(bn, pr + 1); else load_bm(bm0, 2);
+          load_h(h0, 2, 2 * pr, 2 * pr + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          cross_step(b, xa, pr);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // column 2 (steps 6..8); meanwhile the operands of pairs 3-4: row r | row r + 1 of column 2 (the last one repeats
+        // its row: that slot meets zero weights, but must hold finite numbers)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          BM& b = (dy & 1) ? bm1 : bm0;
+          BM& bn = (dy & 1) ? bm0 : bm1;
+          if (dy < 2) load_bm(bn, (dy + 1) * 3 + 2); else load_bx(bx1, 3);
+#pragma unroll
+          for (int r = 2 * dy; r < 2 * dy + 2 && r < R; ++r) xa[r] = load_x(2, r, 2, r + 1 < R ? r + 1 : r);
+          __builtin_amdgcn_sched_barrier(0);
+          main_step(b, h0, dy, false);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        load_bx(bx0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        cross_step(bx1, xa, 0);      // pair 3: taps (0, 2) + (1, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        cross_step(bx0, xa, 2);      // pair 4: tap (2, 2) + nothing
+        __builtin_amdgcn_sched_barrier(0);
+        WS_STAMP(1)
+        continue;
+      }
       AFrag fa0, fa1;
       BFrag fb0, fb1;
       load_a(fa0, halo, 0);
@@ -1019,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
             }
         } else {
           const float16v pair[2] = {acc[2 * m2][j], acc[2 * m2 + 1][j]};
-          ws_epilogue<P, 2, POOL, HEAD>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
+          ws_epilogue<P, 2, POOL, HEAD, X8>(a, pair, sb_lds, head_lds, n, y0 + cw * MW + 2 * m2, x0, ct * BN + j * 32, lane);
         }
       }
     WS_STAMP(2)

@@ -102,6 +102,7 @@ struct ProfRec {
 struct unetpp_engine {
   unetpp_config cfg{};
   int P = 2;
+  bool x8 = false;                // UNETPP_PREC_EXACT8: P = 2 records with 8-bit cross-term planes (conv3x3_ws.h)
   int mb = 1;
   int num_cus = 256;
   std::string err;
@@ -246,34 +247,39 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 }
 
 // wave-specialised kernel (conv3x3_ws.h): 16-row tiles (Cout = 32) or 8-row tiles (Cout % 64 == 0), one persistent workgroup per CU
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4, bool X8 = false>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
-  using C = WsCfg<P, UPF, C0F, NW, MW>;
+  using C = WsCfg<P, UPF, C0F, NW, MW, X8>;
   a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
   const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
-  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW>;
+  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW, X8>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_ws(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
+template <bool X8>
+hipError_t launch_ws_x(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
   if (P != 2 || (upf && (pool || head)) || (pool && head)) return hipErrorInvalidValue;
   if (a.Cout >= 64 && a.Cout % 64 == 0) {      // 8-row tiles, two 32-channel blocks per consumer wave, Cout / 64 channel tiles
     if (head || c0f) return hipErrorInvalidValue;
-    if (upf) return launch_ws_k<2, false, false, true, false, 2, 2>(cx, a, s);
-    if (pool) return launch_ws_k<2, true, false, false, false, 2, 2>(cx, a, s);
-    return launch_ws_k<2, false, false, false, false, 2, 2>(cx, a, s);
+    if (upf) return launch_ws_k<2, false, false, true, false, 2, 2, X8>(cx, a, s);
+    if (pool) return launch_ws_k<2, true, false, false, false, 2, 2, X8>(cx, a, s);
+    return launch_ws_k<2, false, false, false, false, 2, 2, X8>(cx, a, s);
   }
   if (a.Cout != 32) return hipErrorInvalidValue;
-  if (c0f) return (pool && !head && !upf && a.nchunks == 2) ? launch_ws_k<2, true, false, false, true>(cx, a, s) : hipErrorInvalidValue;
-  if (upf) return launch_ws_k<2, false, false, true>(cx, a, s);
-  if (head) return launch_ws_k<2, false, true, false>(cx, a, s);
-  if (pool) return launch_ws_k<2, true, false, false>(cx, a, s);
-  return launch_ws_k<2, false, false, false>(cx, a, s);
+  if (c0f) return (pool && !head && !upf && a.nchunks == 2) ? launch_ws_k<2, true, false, false, true, 1, 4, X8>(cx, a, s) : hipErrorInvalidValue;
+  if (upf) return launch_ws_k<2, false, false, true, false, 1, 4, X8>(cx, a, s);
+  if (head) return launch_ws_k<2, false, true, false, false, 1, 4, X8>(cx, a, s);
+  if (pool) return launch_ws_k<2, true, false, false, false, 1, 4, X8>(cx, a, s);
+  return launch_ws_k<2, false, false, false, false, 1, 4, X8>(cx, a, s);
+}
+
+hipError_t launch_ws(const LaunchCtx& cx, int P, bool x8, const ConvArgs& a, bool pool, bool head, bool upf, bool c0f, hipStream_t s) {
+  return x8 ? launch_ws_x<true>(cx, P, a, pool, head, upf, c0f, s) : launch_ws_x<false>(cx, P, a, pool, head, upf, c0f, s);
 }
 
 template <int P, int KC, int NW, int MW, int WAVES>
@@ -458,13 +464,13 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // Level 0 (Cout = 32: narrow tiles, HBM co-bound): the decoder conv interpolates its `up` channels itself from
     // the low-res tensor (conv3x3_mfma.h, UPF) -- no upsample launch, no `up` tensor.  UNETPP_NO_UPF=1 keeps the
     // separate kernel (A/B measurements).
-    const bool upf = !getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && !getenv("UNETPP_NO_UPF1")));
+    const bool upf = e->x8 || (!getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && !getenv("UNETPP_NO_UPF1"))));
     // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
     // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
     const char* tl = getenv("UNETPP_TAPMM");
     // (the GEMM's 128-wide virtual-channel tiles need 9 * Cout % 128 == 0: levels 2 and 3; at level 1 the fp32
     // side tensors would be 0.9 GB per step and the path measured slower anyway)
-    const bool tapmm = e->P == 2 && l >= 1 && (9 * NB[l]) % TapmmCfg::TN == 0 && strchr(tl ? tl : "23", '0' + l) != nullptr;
+    const bool tapmm = e->P == 2 && !e->x8 && l >= 1 && (9 * NB[l]) % TapmmCfg::TN == 0 && strchr(tl ? tl : "23", '0' + l) != nullptr;
     if (tapmm) {
       snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
       const int yt = b.tensor_raw(std::string(tn) + "y", (size_t)9 * NB[l] * 4, l + 1);
@@ -572,11 +578,17 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (cfg->max_batch < 1 || cfg->max_h < mult || cfg->max_w < mult || cfg->max_h % mult || cfg->max_w % mult)
     return fail(nullptr, UNETPP_E_INVALID, "max shape (%d,%d,%d): batch>=1 and H,W positive multiples of %d required",
                 cfg->max_batch, cfg->max_h, cfg->max_w, mult);
-  if (cfg->precision != UNETPP_PREC_EXACT && cfg->precision != UNETPP_PREC_FAST)
+  if (cfg->precision != UNETPP_PREC_EXACT && cfg->precision != UNETPP_PREC_FAST && cfg->precision != UNETPP_PREC_EXACT8)
     return fail(nullptr, UNETPP_E_INVALID, "precision=%d unknown", cfg->precision);
+  if (cfg->precision == UNETPP_PREC_EXACT8) {
+    // EXACT8 exists in the wave-specialised kernels only: no lock-step / unfused alternatives to switch to
+    if (cfg->arch != UNETPP_ARCH_NESTED) return fail(nullptr, UNETPP_E_UNSUPPORTED, "precision EXACT8 is built for NestedUNet only");
+    for (const char* sw : {"UNETPP_NO_WS", "UNETPP_NO_WS64", "UNETPP_WS_MAX_COUT", "UNETPP_NO_C0F", "UNETPP_NO_UPF", "UNETPP_NO_UPF1"})
+      if (getenv(sw)) return fail(nullptr, UNETPP_E_UNSUPPORTED, "%s has no meaning with precision EXACT8", sw);
+  }
   // the conv loader addresses one image of one tensor with 32-bit byte offsets (buffer loads): the largest
   // full-resolution tensor has 64 channels x (1 or 2) fp16 planes
-  if ((double)cfg->max_h * cfg->max_w * 64 * 2 * (cfg->precision == UNETPP_PREC_EXACT ? 2 : 1) >= 2147483648.0)
+  if ((double)cfg->max_h * cfg->max_w * 64 * 2 * (cfg->precision == UNETPP_PREC_FAST ? 1 : 2) >= 2147483648.0)
     return fail(nullptr, UNETPP_E_UNSUPPORTED, "max shape %dx%d too large for 32-bit tensor offsets", cfg->max_h, cfg->max_w);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -594,7 +606,8 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   e->use_ws = !getenv("UNETPP_NO_WS");
   e->ws64 = e->use_ws && !getenv("UNETPP_NO_WS64");
   if (const char* mc = getenv("UNETPP_WS_MAX_COUT")) e->ws_max_cout = atoi(mc);
-  e->P = cfg->precision == UNETPP_PREC_EXACT ? 2 : 1;
+  e->P = cfg->precision == UNETPP_PREC_FAST ? 1 : 2;
+  e->x8 = cfg->precision == UNETPP_PREC_EXACT8;
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
   e->nstreams = std::max(1, std::min(4, cfg->streams));
   if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
@@ -616,6 +629,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   for (size_t i = 0; i < e->convs.size(); ++i) {
     ConvLayer& L = e->convs[i];
     size_t wb = (size_t)(L.cout / (32 * L.NW)) * L.nchunks * P * 9 * L.KC * (32 * L.NW) * sizeof(half_t);
+    if (e->x8) wb = (size_t)(L.cout / (32 * L.NW)) * L.nchunks * 38 * (32 * L.NW) * 16;      // WsCfg::SLAB_BYTES with X8
     wpk_off[i] = total; total += align_up(wb, 256);
     sc_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
     mu_off[i] = total; total += align_up(L.cout * sizeof(float), 256);
@@ -702,6 +716,13 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     const float* w = e->blob + L.w_off;
     hipLaunchKernelGGL(weight_scale_kernel, dim3(L.cout), dim3(256), 0, s, w, L.cin_real * 9, e->blob + L.b_off, L.mult, L.scale, e->d_status);
     const int BN = 32 * L.NW;
+    if (e->x8) {
+      if ((int)(&L - &e->convs[0]) == e->c0f_conv1) continue;      // conv0_0.conv1 runs in the producers (conv0_pack_kernel below)
+      const long long units = (long long)(L.cout / BN) * L.nchunks * 38 * BN;
+      hipLaunchKernelGGL(weight_pack_x8_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real, L.cout, BN,
+                         L.nchunks, (char*)L.wpk, units);
+      continue;
+    }
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real,
                        L.cout, P, L.KC, BN, L.nchunks, L.wpk, units, layer_uses_ws(e, L) ? 1 : 0);
@@ -907,10 +928,10 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
         auto tf = [](bool v) { return v ? "true" : "false"; };
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2);
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2, tf(e->x8));
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
-          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, a, L.do_pool, head, L.upf, L.c0f, s)
+          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
 #ifdef UNETPP_WS_DBG
@@ -1190,7 +1211,8 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   HIP_TRY(e, hipDeviceSynchronize());
   HIP_TRY(e, hipMalloc((void**)&tmp, total * sizeof(float)));
   const half_t* src = (const half_t*)(e->arena + e->last_slot_off + t->off);
-  if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
+  if (e->x8) hipLaunchKernelGGL(unpack_nchw_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
+  else if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
   else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
   hipError_t st = hipMemcpy(host_out, tmp, total * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(tmp);

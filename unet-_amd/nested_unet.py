@@ -32,8 +32,8 @@ class NestedUNet:
             raise NotImplementedError("pretrained_encoder=True is unsupported by the MI355X engine")
         if input_channels != 3:
             raise NotImplementedError("input_channels must be 3")
-        if precision not in ("exact", "fast"):
-            raise ValueError("precision must be 'exact' or 'fast'")
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be 'exact', 'exact8' or 'fast'")
         self.num_classes = int(num_classes)
         self.input_channels = int(input_channels)
         self.deep_supervision = bool(deep_supervision)
@@ -123,7 +123,7 @@ class NestedUNet:
         self._max_hw = (max(self._max_hw[0], h), max(self._max_hw[1], w))
         lib = _lib.load()
         cfg = _lib.Config(self.num_classes, self.input_channels, self._max_batch, self._max_hw[0], self._max_hw[1],
-                          _lib.PREC_EXACT if self.precision == "exact" else _lib.PREC_FAST, self._device_index,
+                          _lib.PRECISIONS[self.precision], self._device_index,
                           self._micro_batch, self._streams, self._ARCH)
         handle = ctypes.c_void_p()
         rc = lib.unetpp_create(ctypes.byref(cfg), ctypes.byref(handle))
