@@ -30,6 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+DTYPES = {"exact": "f16 (MFMA operands split hi+lo, 3 MFMAs per product, f32 accumulate)",
+          "exact8": "f16 + fp8 (hi*hi in fp16 MFMA; lo*w and x*w_lo from e5m2 / e4m3 operands in one block-scaled K=64 MFMA per tap "
+                    "pair; f32 accumulate)",
+          "fast": "f16"}
 MFMA_F16_PEAK_TFLOPS = 2500.0                       # dense fp16 MFMA, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 
@@ -85,19 +89,25 @@ def launch_ranks(args) -> int:
         port = s.getsockname()[1]
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
+    # host threads per rank (torch's intra-op pool, only used by the CPU-side helpers): the host's cores shared out
+    # among the ranks, unless the caller has set OMP_NUM_THREADS (N ranks x all cores each would oversubscribe the host)
+    threads = str(max(1, min(16, (os.cpu_count() or n) // n)))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UNETPP_BENCH_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", threads)
         # rank 0's stdout carries the JSON line; the other ranks' stdout joins stderr so the parent prints one line
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # rank 0's pipe is drained while it runs: a library that writes more than a pipe buffer to stdout must not block it
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.extend(iter(procs[0].stdout.readline, "")), daemon=True)
+    reader.start()
     deadline = time.time() + float(os.environ.get("UNETPP_BENCH_TIMEOUT", "1500"))
     first_fail = None
-    out0 = None
     while True:
         codes = [p.poll() for p in procs]
-        if out0 is None and codes[0] is not None:
-            out0 = procs[0].stdout.read()
         if all(c is not None for c in codes):
             break
         bad = [c for c in codes if c not in (None, 0)]
@@ -114,10 +124,10 @@ def launch_ranks(args) -> int:
                     p.kill()
             break
         time.sleep(0.2)
-    if out0 is None:
-        out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    reader.join(timeout=10)
+    out0 = "".join(chunks)
     codes = [p.poll() if p.poll() is not None else -9 for p in procs]
-    for line in (out0 or "").splitlines():     # the JSON line goes to stdout, library chatter ("[Gloo] Rank 0 ...") to stderr
+    for line in out0.splitlines():             # the JSON line goes to stdout, library chatter ("[Gloo] Rank 0 ...") to stderr
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     worst = max((abs(c) for c in codes), default=0)
     if worst:
@@ -127,7 +137,7 @@ def launch_ranks(args) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(sd, syn, arch, C, H, W, n_frames, gpu_model, torch):
+def cpu_baseline(sd, syn, arch, C, H, W, n_frames, gpu_model, torch, ref=None):
     """The oracle's torch-CPU restatement (what the reference's --device cpu path executes), batch 1
     per call like the reference frame loop, timed on this host's cores; the same frames go through
     the GPU engine and the two masks are compared."""
@@ -137,6 +147,11 @@ def cpu_baseline(sd, syn, arch, C, H, W, n_frames, gpu_model, torch):
     fwd = oracle.torch_forward if arch == "nested" else oracle.simple_unet_torch_forward
     frames = syn.make_frames_u8(n_frames, H, W, "smooth", 4321)
     x = syn.frames_to_chw_f32(frames)
+    if ref is not None and ref.get("n", 0) >= n_frames:        # the CPU side of these frames was computed (and timed) for the headline leg
+        ref_logits, ref_masks = ref["logits"][:n_frames], ref["masks"][:n_frames]
+        mask, logits = gpu_model.segment(torch.from_numpy(x).cuda(), return_logits=True)
+        torch.cuda.synchronize()
+        return None, _parity(oracle, logits.cpu().numpy(), mask.cpu().numpy(), ref_logits, ref_masks, n_frames, gpu_model)
 
     def segment(xi):
         lg = fwd(sd, xi)
@@ -162,20 +177,26 @@ def cpu_baseline(sd, syn, arch, C, H, W, n_frames, gpu_model, torch):
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     ref_logits = np.concatenate([r[0] for r in res]); ref_masks = np.concatenate([r[1] for r in res])
+    if ref is not None:
+        ref.update(n=n_frames, logits=ref_logits, masks=ref_masks)
     mask, logits = gpu_model.segment(torch.from_numpy(x).cuda(), return_logits=True)
     torch.cuda.synchronize()
-    err = float(np.abs(logits.cpu().numpy() - ref_logits).max())
-    flips = mask.cpu().numpy() != ref_masks
-    margin = oracle.top2_margin(ref_logits)
     base = {"value": n_frames / dt, "unit": "frames/s", "cores": int(best_nt), "kind": "port",
             "sample": f"{n_frames} frames of {C}-class {H}x{W}, batch 1 per call, torch {torch.__version__} CPU fp32 "
                       f"(oracle/unetpp_oracle.py {fwd.__name__} + softmax/argmax), host cpu_count={os.cpu_count()}, "
                       f"threads tried (frames/s): " + ", ".join(f"{k}:{v:.2f}" for k, v in sorted(trials.items()))}
-    parity = {"frames": n_frames, "max_abs_logit_err": err, "mask_flips": int(flips.sum()),
-              "mask_pixels": int(flips.size),
-              "flips_outside_near_ties": int((flips & (margin > 2 * err + 1e-7)).sum()), "logit_tol": 1e-3,
-              "range_status": int(gpu_model.status())}
-    return base, parity
+    return base, _parity(oracle, logits.cpu().numpy(), mask.cpu().numpy(), ref_logits, ref_masks, n_frames, gpu_model)
+
+
+def _parity(oracle, logits, mask, ref_logits, ref_masks, n_frames, gpu_model):
+    import numpy as np
+    err = float(np.abs(logits - ref_logits).max())
+    flips = mask != ref_masks
+    margin = oracle.top2_margin(ref_logits)
+    return {"frames": n_frames, "max_abs_logit_err": err, "mask_flips": int(flips.sum()),
+            "mask_pixels": int(flips.size), "largest_margin_at_a_flip": float(margin[flips].max()) if flips.any() else 0.0,
+            "flips_outside_near_ties": int((flips & (margin > 2 * err + 1e-7)).sum()), "logit_tol": 1e-3,
+            "range_status": int(gpu_model.status())}
 
 
 def measured_traffic(kernel, workload_key):
@@ -335,17 +356,22 @@ def run_rank(args) -> int:
     if world > 1:
         barrier()                                       # first collective: sets the communicator up, untimed
     model = make_model(args.precision, timed_bcast=True)
-    dt, own_dt, _ = timed(model, args.steps, args.warmup, profile=False)      # `value`: no per-launch events in the timed region
+    # `value`: no per-launch events in the timed region.  The timed loop (W warm-up + exactly K steps between barriers) runs
+    # three times; the median sample is reported (boxes of the pool and even consecutive loops differ by a few percent),
+    # all three are printed.
+    samples = [timed(model, args.steps, args.warmup if i == 0 else 1, profile=False) for i in range(1 if dry else 3)]
+    dt, own_dt, _ = sorted(samples, key=lambda t: t[0])[len(samples) // 2]
     fps = B * world * args.steps / dt
     gflop = algorithmic_gflop(arch, C, H, W)
 
     # ---- roofline of the dominant kernel: a second, short loop with one HIP event per launch boundary, recorded on
     # the launch stream by the engine (unetpp_profile_*); its per-step time is reported next to the un-profiled one
-    roofline, agg, prof_ms = None, {}, None
+    roofline, agg, prof_ms, executed_gflop = None, {}, None, None
     if not dry:
         psteps = max(2, min(args.steps, 10))
         pdt, _, recs = timed(model, psteps, 1, profile=True)
         prof_ms = pdt / psteps * 1e3
+        executed_gflop = sum(r[2] for r in recs) / psteps / B / 1e9        # flops of the launches the engine really made
         for name, ms, fl, by in recs:
             k = name.split("|")[-1]
             a = agg.setdefault(k, [0.0, 0.0, 0.0, 0])
@@ -354,7 +380,9 @@ def run_rank(args) -> int:
         if dom:
             k, (ms, fl, by, cnt) = dom
             tf = fl / (ms * 1e-3) / 1e12
-            mfma_mult = 3.0 if args.precision == "exact" else 1.0      # exact mode issues 3 MFMAs per product
+            # matrix-pipe cycles per product relative to one fp16 MFMA: exact issues 3 MFMAs; exact8 per 16-channel chunk
+            # 9 fp16 MFMAs of 32 cycles + 5 scaled fp8 ones of 64 (two taps each) = 608 / 288
+            mfma_mult = {"exact": 3.0, "exact8": 608.0 / 288.0, "fast": 1.0}[args.precision]
             wkey = f"{arch}-c{C}-{H}x{W}-b{B}-{args.precision}"
             traffic, tsrc = measured_traffic(k, wkey)
             roofline = {"bound": "mfma", "kernel": k, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -373,14 +401,21 @@ def run_rank(args) -> int:
                   else f"frames/sec {H}x{W} {C}-class {name} inference",
         "value": None if dry else fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if args.precision == "fast" else "f16 (MFMA operands split hi+lo, 3 MFMAs per product, f32 accumulate)",
+        "dtype": DTYPES[args.precision],
         "data": "synthetic" if not dry else "none (--no-engine control-flow rehearsal: nothing was computed)",
         "config": {"workload": f"{name} {C}-class {H}x{W} batch={B}/GPU fp16-MFMA on {world} MI355X, synthetic frames, "
                                f"f32 NCHW in HBM -> uint8 mask in HBM",
                    "arch": arch, "precision": args.precision, "frames_per_gpu": B, "global_batch": B * world,
                    "micro_batch": args.micro_batch or B, "parallelism": f"frame-sharded x{world}, weights replicated (RCCL bcast)"},
+        "ms_per_step_samples": [t[0] / args.steps * 1e3 for t in samples],
+        # reference-equivalent work (what unetpp.py:104-119 multiplies) and what this build executes (the decoder conv1 of
+        # levels 2-3 at low resolution: half their flops), both against the dense fp16 MFMA peak
         "whole_net": {"gflop_per_frame": gflop, "achieved_tflops": fps * gflop / 1e3,
-                      "frac_of_f16_mfma_peak": fps * gflop / 1e3 / (MFMA_F16_PEAK_TFLOPS * world)},
+                      "frac_of_f16_mfma_peak": fps * gflop / 1e3 / (MFMA_F16_PEAK_TFLOPS * world),
+                      "flops_counted": "reference-equivalent",
+                      "executed_gflop_per_frame": executed_gflop,
+                      "executed_tflops": None if executed_gflop is None else fps * executed_gflop / 1e3,
+                      "executed_frac": None if executed_gflop is None else fps * executed_gflop / 1e3 / (MFMA_F16_PEAK_TFLOPS * world)},
         "roofline": roofline,
         "build": _lib.load().unetpp_version().decode() if not dry else "no-engine",
     }
@@ -405,9 +440,10 @@ def run_rank(args) -> int:
                               "launches_per_step": v[3] / roofline["profiled_steps"]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
 
+    ref_cache = {}
     # ---- CPU baseline + parity of the measured mode on the same frames (rank 0, N=1 only)
     if rank == 0 and world == 1 and args.cpu_frames > 0 and not dry:
-        base, parity = cpu_baseline(sd, syn, arch, C, H, W, args.cpu_frames, model, torch)
+        base, parity = cpu_baseline(sd, syn, arch, C, H, W, args.cpu_frames, model, torch, ref=ref_cache)
         out["cpu_baseline"] = base
         out["parity"] = parity
     else:
@@ -450,15 +486,23 @@ def run_rank(args) -> int:
 
     # ---- informational second leg: the other precision mode on the same workload
     if not args.no_fast_leg and world == 1 and not dry:
-        other = "fast" if args.precision == "exact" else "exact"
         del model
-        m2 = make_model(other)
-        dt2, _, _ = timed(m2, args.steps, args.warmup, profile=False)
-        leg = {"precision": other, "value": B * args.steps / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3}
-        if rank == 0 and args.cpu_frames > 0:
-            _, p2 = cpu_baseline(sd, syn, arch, C, H, W, min(args.cpu_frames, 2), m2, torch)
-            leg["parity"] = p2
-        out["other_precision"] = leg
+        legs = {}
+        for other in [p for p in (("exact", "exact8", "fast") if arch == "nested" else ("exact", "fast")) if p != args.precision]:
+            m2 = make_model(other)
+            dt2, _, _ = timed(m2, args.steps, args.warmup, profile=False)
+            leg = {"precision": other, "dtype": DTYPES[other], "value": B * args.steps / dt2, "unit": "frames/s",
+                   "ms_per_step": dt2 / args.steps * 1e3}
+            if rank == 0 and args.cpu_frames > 0:
+                # exact8 is a parity-gated mode (logit_tol 1e-3): its leg is checked on as many frames as the headline
+                _, p2 = cpu_baseline(sd, syn, arch, C, H, W, args.cpu_frames if other == "exact8" else min(args.cpu_frames, 2), m2, torch,
+                                     ref=ref_cache)
+                leg["parity"] = p2
+                leg["passes_parity_gate"] = bool(p2["max_abs_logit_err"] < p2["logit_tol"] and p2["flips_outside_near_ties"] == 0)
+            legs[other] = leg
+            del m2
+        out["legs"] = legs
+        out["other_precision"] = legs.get("fast") or legs.get("exact")       # (name kept from earlier rounds)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -478,7 +522,7 @@ def main() -> int:
     ap.add_argument("--classes", type=int, default=None)
     ap.add_argument("--arch", default="nested", choices=["nested", "simple"],
                     help="nested = NestedUNet / UNet++ (the BASELINE metric); simple = SimpleUNet (SURVEY 8(f) row 3)")
-    ap.add_argument("--precision", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--precision", default="exact", choices=["exact", "exact8", "fast"])
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames timed on the CPU baseline (0 = skip)")

@@ -355,13 +355,23 @@ __global__ void head_generic_kernel(const half_t* __restrict__ x, int Cx, const 
   for (int c = 0; c < HEAD_FUSED_MAX_CLASSES; ++c) lg[c] = (c < C) ? head_ws[C * Cx + c] : -INFINITY;
   const int nblk = Cx >> 4;
   for (int blk = 0; blk < nblk; ++blk) {
-    const half8* px = (const half8*)(x + ((((size_t)n * nblk + blk) * hw + p) * P) * 16);
+    const half8* px = (const half8*)(x + ((((size_t)n * nblk + blk) * hw + p) * (P == 3 ? 2 : P)) * 16);
     float v[16];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       half8 hi = px[g];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[g * 8 + e] = (float)hi[e];
+      if (P == 3) {      // EXACT8 record: value = hi + 2^-8 lo8, lo8 bytes of channels 8 g + 4 q + i in word 2 q of piece 2 + g
+        const u32x4 w8 = __builtin_bit_cast(u32x4, px[2 + g]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          v[g * 8 + 4 * q + 0] += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)w8[2 * q], X8_LO_MUL, 0);
+          v[g * 8 + 4 * q + 1] += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)w8[2 * q], X8_LO_MUL, 1);
+          v[g * 8 + 4 * q + 2] += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)w8[2 * q], X8_LO_MUL, 2);
+          v[g * 8 + 4 * q + 3] += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)w8[2 * q], X8_LO_MUL, 3);
+        }
+      }
       if (P == 2) {
         half8 lo = px[2 + g];
 #pragma unroll

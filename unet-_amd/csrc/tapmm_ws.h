@@ -46,6 +46,11 @@ struct TapmmCfg {
   static_assert(LDS_BYTES <= 160 * 1024 && AHEAD + 2 <= SLOTS, "ring");
 };
 
+// X8 (precision EXACT8, conv3x3_ws.h): the stages hold the 8-bit planes where the lo planes were -- pixels [lo8 | x8]
+// (conv3x3_mfma.h), weights [wh8 | wl8] (tapw_pack_kernel) -- and the two cross terms of TWO consecutive stages (2 x 16
+// channels x 2 kinds = K 64) go through one v_mfma_scale_f32_32x32x64_f8f6f4: bytes 0-15 of a lane from stage g, bytes 16-31
+// from stage g + 1.  Per stage pair and output tile: 2 fp16 MFMAs + 1 scaled one (128 pipe cycles) instead of 6 (192).
+template <bool X8>
 __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
   using C = TapmmCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,6 +159,45 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
   int g = 0;
   Frag f0, f1;
   bool have_f0 = false;                                             // fragments of stage g already in f0 / f1 (parity of g)
+  // X8: the fp16 hi fragments of a stage (h0: even stages, h1: odd ones) and the 8-bit operands of a stage PAIR
+  struct HFrag { half8 a[C::MT], b[C::NTL]; };
+  HFrag h0, h1;
+  int8v xa[C::MT], xb[C::NTL];      // 8-bit operands of a stage pair: bytes 0-15 from stage g, bytes 16-31 from stage g + 1
+  auto load_h = [&](HFrag& f, int ring) {
+    const char* st = smem + ring * C::STAGE_BYTES;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) f.a[mt] = *(const half8*)(st + a_off[mt]);
+#pragma unroll
+    for (int nt = 0; nt < C::NTL; ++nt) f.b[nt] = *(const half8*)(st + b_off + nt * 2048);
+  };
+  auto load_x = [&](int ring0, int ring1) {
+    const char* s0 = smem + ring0 * C::STAGE_BYTES;
+    const char* s1 = smem + ring1 * C::STAGE_BYTES;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+      const int4v lo = *(const int4v*)(s0 + a_off[mt] + 512), hi = *(const int4v*)(s1 + a_off[mt] + 512);
+      xa[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int nt = 0; nt < C::NTL; ++nt) {
+      const int4v lo = *(const int4v*)(s0 + b_off + nt * 2048 + 1024), hi = *(const int4v*)(s1 + b_off + nt * 2048 + 1024);
+      xb[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto main_mfma = [&](const HFrag& f) {
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NTL; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.b[nt], f.a[mt], acc[mt][nt], 0, 0, 0);
+  };
+  auto cross_mfma = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NTL; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb[nt], xa[mt], acc[mt][nt], 0 /* e4m3 */, 1 /* e5m2 */, 0, X8_SCALE_W, 0, X8_SCALE_A);
+      }
+  };
   for (int tile = slot; tile < total_tiles; tile += G) {
     int n, q0, vt;
     decode(tile, n, q0, vt);
@@ -164,6 +208,27 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const bool last_tile = tile + G >= total_tiles;
+    if constexpr (X8) {
+      for (int s = 0; s < nst; s += 2) {
+        lds_barrier();                                              // stages g, g+1 landed
+        if (!have_f0) { load_h(h0, g % C::SLOTS); have_f0 = true; }
+        load_x(g % C::SLOTS, (g + 1) % C::SLOTS);
+        load_h(h1, (g + 1) % C::SLOTS);
+        __builtin_amdgcn_sched_barrier(0);
+        main_mfma(h0);
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+        lds_barrier();                                              // stages g, g+1 landed; every read of stage g-1 is done
+        const bool more = !(last_tile && s + 2 >= nst);
+        if (more) load_h(h0, (g + 1) % C::SLOTS);
+        have_f0 = more;
+        __builtin_amdgcn_sched_barrier(0);
+        cross_mfma();                                               // the pair (g-1, g)
+        main_mfma(h1);
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+      }
+    } else
     for (int s = 0; s < nst; s += 2) {                              // two stages per trip: static register sets
       lds_barrier();                                                // stages g, g+1 landed
       if (!have_f0) { load_frags(f0, g % C::SLOTS); have_f0 = true; }
@@ -207,8 +272,10 @@ __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
 
 // canonical conv1 weight [Cout][Cs + Cup][3][3] fp32 -> tapmm's A operand (the up channels only):
 // [v-tile 128][k16][vt 4][plane][kg 2][32 v][8 halves], virtual channel v = tap * Cout + co, scaled by mult[co]
+// x8: plane 1 holds, per (h = former k-group, v), the 16 e4m3 bytes [wh8 x 4 | wl8 x 4 | wh8 x 4 | wl8 x 4] of input channels
+// 16 ks + 8 h + 0..7 (weight_pack_x8_kernel's encoding: wh8 = e4m3(2^-6 ws), wl8 = e4m3(2^5 (ws - fp16(ws))))
 __global__ void tapw_pack_kernel(const float* __restrict__ w, const float* __restrict__ mult, int Cout, int Cs, int Cup,
-                                 half_t* __restrict__ out, long long units) {
+                                 half_t* __restrict__ out, long long units, int x8) {
   const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   long long t = u;
@@ -222,12 +289,28 @@ __global__ void tapw_pack_kernel(const float* __restrict__ w, const float* __res
   const int v = v128 * 128 + vt * 32 + vv;
   const int tap = v / Cout, co = v - tap * Cout;
   half8 r;
+  float val[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = ks * 16 + kg * 8 + e;
-    const float val = w[((size_t)co * (Cs + Cup) + Cs + c) * 9 + tap] * mult[co];
-    const half_t hi = (half_t)val;
-    r[e] = pl == 0 ? hi : (half_t)(val - (float)hi);
+    val[e] = w[((size_t)co * (Cs + Cup) + Cs + c) * 9 + tap] * mult[co];
+    const half_t hi = (half_t)val[e];
+    r[e] = pl == 0 ? hi : (half_t)(val[e] - (float)hi);
+  }
+  if (x8 && pl == 1) {
+    unsigned wd[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int a8 = 0, b8 = 0;
+      float hi4[4], lo4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { hi4[i] = val[4 * q + i] * 0.015625f; lo4[i] = (val[4 * q + i] - (float)(half_t)val[4 * q + i]) * 32.0f; }
+      a8 = __builtin_amdgcn_cvt_pk_fp8_f32(hi4[0], hi4[1], a8, false); a8 = __builtin_amdgcn_cvt_pk_fp8_f32(hi4[2], hi4[3], a8, true);
+      b8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo4[0], lo4[1], b8, false); b8 = __builtin_amdgcn_cvt_pk_fp8_f32(lo4[2], lo4[3], b8, true);
+      wd[2 * q] = (unsigned)a8; wd[2 * q + 1] = (unsigned)b8;
+    }
+    *(u32x4*)(out + u * 8) = (u32x4){wd[0], wd[1], wd[2], wd[3]};
+    return;
   }
   *(half8*)(out + u * 8) = r;
 }

@@ -464,13 +464,15 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // Level 0 (Cout = 32: narrow tiles, HBM co-bound): the decoder conv interpolates its `up` channels itself from
     // the low-res tensor (conv3x3_mfma.h, UPF) -- no upsample launch, no `up` tensor.  UNETPP_NO_UPF=1 keeps the
     // separate kernel (A/B measurements).
+    // (EXACT8: every level that does not take the low-resolution GEMM below interpolates in its loader -- the separate
+    // upsample kernel and the two-source loader do not know the 8-bit planes)
     const bool upf = e->x8 || (!getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && !getenv("UNETPP_NO_UPF1"))));
     // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
     // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
     const char* tl = getenv("UNETPP_TAPMM");
     // (the GEMM's 128-wide virtual-channel tiles need 9 * Cout % 128 == 0: levels 2 and 3; at level 1 the fp32
     // side tensors would be 0.9 GB per step and the path measured slower anyway)
-    const bool tapmm = e->P == 2 && !e->x8 && l >= 1 && (9 * NB[l]) % TapmmCfg::TN == 0 && strchr(tl ? tl : "23", '0' + l) != nullptr;
+    const bool tapmm = e->P == 2 && l >= 1 && (9 * NB[l]) % TapmmCfg::TN == 0 && strchr(tl ? tl : "23", '0' + l) != nullptr;
     if (tapmm) {
       snprintf(nm, sizeof nm, "conv%d_%d", l, 4 - l);
       const int yt = b.tensor_raw(std::string(tn) + "y", (size_t)9 * NB[l] * 4, l + 1);
@@ -732,7 +734,7 @@ static int repack(unetpp_engine* e, hipStream_t s) {
     const int cs = e->tensors[L.in].C, cup = L.cin_real - cs;
     const long long units = (long long)9 * L.cout * cup * P / 8;
     hipLaunchKernelGGL(tapw_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, e->blob + L.w_off, L.mult, L.cout, cs,
-                       cup, L.tapw, units);
+                       cup, L.tapw, units, e->x8 ? 1 : 0);
   }
   if (e->c0f_conv1 >= 0) {
     const ConvLayer& L1 = e->convs[e->c0f_conv1];
@@ -964,11 +966,12 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
           const int tiles = nb * ((t.hw + TapmmCfg::TM - 1) / TapmmCfg::TM) * (t.Nv / TapmmCfg::TN);
           const double M = (double)nb * t.hw;
           char lbl[96];
-          snprintf(lbl, sizeof lbl, "%s.up-gemm|tapmm_ws_kernel", L.name.c_str());
+          snprintf(lbl, sizeof lbl, "%s.up-gemm|tapmm_ws_kernel<%s>", L.name.c_str(), e->x8 ? "true" : "false");
           Lx.run(lbl, 2.0 * M * cup * t.Nv, M * cup * 2.0 * P + M * t.Nv * 4.0 + (double)t.Nv * cup * 2.0 * P, [&] {
-            hipError_t st = allow_full_lds((const void*)tapmm_ws_kernel, e->cfg.device);
+            auto k = e->x8 ? tapmm_ws_kernel<true> : tapmm_ws_kernel<false>;
+            hipError_t st = allow_full_lds((const void*)k, e->cfg.device);
             if (st != hipSuccess) return st;
-            hipLaunchKernelGGL(tapmm_ws_kernel, dim3((unsigned)std::min(tiles, e->num_cus)), dim3(TapmmCfg::NT), TapmmCfg::LDS_BYTES, s, t);
+            hipLaunchKernelGGL(k, dim3((unsigned)std::min(tiles, e->num_cus)), dim3(TapmmCfg::NT), TapmmCfg::LDS_BYTES, s, t);
             return hipSuccess;
           });
         } else {
@@ -1025,8 +1028,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         double bytes = (double)total * (P * 2.0 * cx + (lg ? 4.0 * C : 0) + (pr ? 4.0 * C : 0) + (mk ? 1 : 0) + (cb ? 1 : 0) + (tpe ? 1 : 0));
         dim3 grid((unsigned)((hw + 255) / 256), (unsigned)nb);
         const size_t lds = (size_t)(C * cx + C) * sizeof(float);
-        Lx.run(P == 2 ? "final+argmax|head_generic_kernel<2>" : "final+argmax|head_generic_kernel<1>", 2.0 * total * cx * C, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(head_generic_kernel<2>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+        Lx.run(e->x8 ? "final+argmax|head_generic_kernel<3>" : P == 2 ? "final+argmax|head_generic_kernel<2>" : "final+argmax|head_generic_kernel<1>", 2.0 * total * cx * C, bytes, [&] {
+          if (e->x8) hipLaunchKernelGGL(head_generic_kernel<3>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
+          else if (P == 2) hipLaunchKernelGGL(head_generic_kernel<2>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
           else hipLaunchKernelGGL(head_generic_kernel<1>, grid, dim3(256), lds, s, tp(op.out), cx, e->blob + e->head_w_off, e->blob + e->head_b_off, C, h, w, lg, pr, mk, cb, tpe, outp->rule, outp->t_cable, outp->t_tape, outp->bg_margin, outp->ct_margin);
           return hipSuccess;
         });
