@@ -55,6 +55,10 @@ struct ConvArgs {
   int tiles_x, tiles_y;  // spatial tiles per image
   int nct;               // Cout / BN
   int nchunks;           // ceil(C0 / KC) + C1 / KC
+  // split-K of the wave-specialised kernel (conv3x3_ws.h): ksplit workgroups per tile, raw fp32 partials, arrival counters
+  int ksplit;            // >= 1, divides nchunks
+  float* kpart;          // [ksplit][tiles][4 consumer waves][MW * NW * 16 * 64] fp32
+  unsigned* kcnt;        // [tiles][4], zero between launches
   // fused 1x1 head + argmax (HEAD variant, Cout == 32 == BN): self.final (unetpp.py:85,119) and the
   // frame-loop tail softmax->argmax->uint8, (pred==1), (pred==2) (infer_two_stage_burr.py:299-304)
   const float* head_w;   // [C][32] fp32

@@ -241,7 +241,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, W = a.W;
   const int tiles_img = a.tiles_x * a.tiles_y;
-  const int total_tiles = a.N * tiles_img * a.nct;      // a.nct = Cout / BN channel tiles per pixel tile
+  // a.nct = Cout / BN channel tiles per pixel tile; a.ksplit (>= 1) = workgroups that share a tile, each with its own
+  // range of K-chunks (small batches: see the split-K notes at the consumers' epilogue)
+  const int KS = a.ksplit;
+  const int total_tiles = a.N * tiles_img * a.nct * KS;
   const int nch0 = (a.C0 + KC - 1) / KC;
   const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
 
@@ -260,10 +263,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   // Tile number -> (channel tile, column, row, image).  A workgroup asks for its slot, then for tiles G apart (or the
   // same tile again): only the first call divides, later ones add G's own decomposition with carries (wave-uniform
   // scalar work; the six divisions per tile used to cost several hundred cycles in each role).
-  int dec_ct = 0, dec_tx = 0, dec_ty = 0, dec_n = 0, dec_t = -1;      // the tile decoded last (per-wave cursor)
-  int g_ct, g_tx, g_ty, g_n;
+  int dec_ks = 0, dec_ct = 0, dec_tx = 0, dec_ty = 0, dec_n = 0, dec_t = -1;      // the tile decoded last (per-wave cursor)
+  int g_ks, g_ct, g_tx, g_ty, g_n;
   {
     int t = G;
+    g_ks = t % KS; t /= KS;
     g_ct = t % a.nct; t /= a.nct;
     g_tx = t % a.tiles_x; t /= a.tiles_x;
     g_ty = t % a.tiles_y;
@@ -272,8 +276,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   auto decode = [&](int t, int& n, int& y0, int& x0) {
     if (t != dec_t) {
       if (dec_t >= 0 && t == dec_t + G) {
-        dec_ct += g_ct;
-        int carry = dec_ct >= a.nct ? 1 : 0;
+        dec_ks += g_ks;
+        int carry = dec_ks >= KS ? 1 : 0;
+        dec_ks -= carry ? KS : 0;
+        dec_ct += g_ct + carry;
+        carry = dec_ct >= a.nct ? 1 : 0;
         dec_ct -= carry ? a.nct : 0;
         dec_tx += g_tx + carry;
         carry = dec_tx >= a.tiles_x ? 1 : 0;
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         dec_n += g_n + carry;
       } else {
         int u = t;
+        dec_ks = u % KS; u /= KS;
         dec_ct = u % a.nct; u /= a.nct;
         dec_tx = u % a.tiles_x; u /= a.tiles_x;
         dec_ty = u % a.tiles_y;
@@ -294,6 +302,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     n = dec_n; x0 = dec_tx * TW; y0 = dec_ty * TH;
   };
   if (slot >= total_tiles) return;                       // whole workgroup: no barrier has been executed yet
+  // (a one-chunk tile has no second barrier to publish the handed-over pair; a split tile has no epilogue to share)
+  const bool handoff = C::HANDOFF && a.nchunks >= 2 && KS == 1;
 
   // ---- C0F: patch loader (producer lanes) and the once-per-launch part of the producers' work
   typedef __attribute__((ext_vector_type(4))) float float4v;
@@ -571,11 +581,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       hyx[it] = (hp < C::NHALO) ? ((hy << 8) | hx) : -1;
     }
     const int cb0 = a.C0 < 16 ? a.C0 : 16;
-    const unsigned plane_bytes0 = (unsigned)(H * W * P * cb0 * 2);
-    const unsigned img_bytes0 = (unsigned)(H * W * P * a.C0 * 2);
+    const unsigned plane_bytes0 = (unsigned)H * (unsigned)W * (unsigned)(P * cb0 * 2);      // < 2^31: unetpp_create's shape limit
+    const unsigned img_bytes0 = (unsigned)H * (unsigned)W * (unsigned)(P * a.C0 * 2);
     const int Hs = H >> 1, Ws = W >> 1;
-    const unsigned plane_bytes1 = (unsigned)(Hs * Ws * P * 16 * 2);
-    const unsigned img_bytes1 = (unsigned)(Hs * Ws * P * a.C1 * 2);
+    const unsigned plane_bytes1 = (unsigned)Hs * (unsigned)Ws * (unsigned)(P * 16 * 2);
+    const unsigned img_bytes1 = (unsigned)Hs * (unsigned)Ws * (unsigned)(P * a.C1 * 2);
     const float up_sh = Hs > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
     const float up_sw = Ws > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f;
 
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 
     auto setup_tile = [&](int n, int y0, int x0) {
       if (y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W) {          // halo rows y0-1 .. y0+TH, columns x0-1 .. x0+TW
-        const unsigned origin = (unsigned)((y0 * W + x0) * P * cb0 * 2);
+        const unsigned origin = ((unsigned)y0 * (unsigned)W + (unsigned)x0) * (unsigned)(P * cb0 * 2);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) voff0[it] = origin + (unsigned)lane_off0[it];   // OOB + origin stays out of range
       } else {
@@ -734,7 +744,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
               if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
               else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
             } else {
-              const half2v hv = __builtin_bit_cast(half2v, hq[r][k][e >> 1]);
+              const unsigned hw = hq[r][k][e >> 1];      // (a scalar first: bit-casting a vector element reads element 0)
+              const half2v hv = __builtin_bit_cast(half2v, hw);
               cc[k] = (float)hv[e & 1];
             }
           }
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       ws_epilogue<P, 2, POOL, HEAD, X8>(a, pair, sb_lds, head_lds, hn, gy0, hx0, cbase, lane);
     };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
-    const bool slabs_stay = a.nchunks == 2 && a.nct == 1;
+    const bool slabs_stay = a.nchunks == 2 && a.nct == 1 && KS == 1;
 #ifdef UNETPP_WS_DBG
     st_t = __builtin_readcyclecounter();
 #endif
@@ -809,7 +820,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       WS_STAMP(7)
       const char* wsrc = (const char*)a.wpk + (size_t)dec_ct * a.nchunks * C::SLAB_BYTES;
       const int tile_ct = dec_ct;
-      for (int c = 0; c < a.nchunks; ++c, ++g) {
+      const int c_begin = dec_ks * (a.nchunks / KS), c_end = c_begin + a.nchunks / KS;       // this workgroup's share of K
+      for (int c = c_begin; c < c_end; ++c, ++g) {
         const int buf = (g & 1) * C::BUF_BYTES;
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 2))
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
         if (!(a.dbg & 128))
 #endif
-        if (C::HANDOFF && c == 1 && have_handoff) handoff_epilogue();     // previous tile's pair: published by the barrier behind chunk 0
+        if (handoff && c == 1 && have_handoff) handoff_epilogue();     // previous tile's pair: published by the barrier behind chunk 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
         if (UPF && c >= nch0) { WS_STAMP(5) } else { WS_STAMP(1) }
         lds_barrier();                                    // chunk g published; the consumers have left buffer (g+1) & 1
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
       hn = n; hy0 = y0; hx0 = x0; hct = tile_ct; have_handoff = true;
     }
-    if (C::HANDOFF && a.nchunks >= 2) {                   // (a one-chunk tile has no second barrier to publish the pair)
+    if (handoff) {
       lds_barrier();                                      // the consumers' last pair is in LDS
       if (have_handoff) handoff_epilogue();
     }
@@ -959,12 +971,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   for (int tile = slot; tile < total_tiles; tile += G) {
     int n, y0, x0;
     decode(tile, n, y0, x0);
-    const int ct = dec_ct;
+    const int ct = dec_ct, ks = dec_ks;
+    const int c_begin = ks * (a.nchunks / KS), c_end = c_begin + a.nchunks / KS;
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        if (a.zinit) {    // accumulators start from the low-resolution half of the layer (tapmm_ws.h); uniform branch
+        if (a.zinit && ks == 0) {    // accumulators start from the low-resolution half of the layer (tapmm_ws.h); uniform branch
           typedef __attribute__((ext_vector_type(4))) float f32x4;
           const int gy = y0 + cw * MW + m, gx = x0 + (lane & 31);
           const bool in = gy < H && gx < W;
@@ -978,9 +991,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           }
         }
       }
-    const bool from_zero = a.zinit == nullptr;
+    const bool from_zero = a.zinit == nullptr || ks != 0;
     WS_STAMP(3)
-    for (int c = 0; c < a.nchunks; ++c, ++g) {
+    for (int c = c_begin; c < c_end; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
       WS_STAMP(0)
       const char* halo = smem + (g & 1) * C::BUF_BYTES;
@@ -1045,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         BX bx0, bx1;
         load_h(h0, 0, 0, R);
         load_bm(bm0, 0);
-        const bool first = c == 0 && from_zero;
+        const bool first = c == c_begin && from_zero;
         // column 0 (taps dy * 3 + 0)
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -1125,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           if (!(a.dbg & 4))
 #endif
           {
-            if (step == 0 && c == 0 && from_zero) run_mfma_first(fa, fb);
+            if (step == 0 && c == c_begin && from_zero) run_mfma_first(fa, fb);
             else run_mfma(fa, fb, dy);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -1137,11 +1150,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
     if (a.dbg & 256) { if (acc[0][0][0] == 12345.f && acc[MW - 1][NW - 1][5] == 7.f) a.status[1] = 1; continue; }
 #endif
+    // ---- split-K (a.ksplit > 1; small batches, where a layer has fewer tiles than the chip has CUs): this wave's raw
+    // accumulators go to its slot of the partial buffer; a counter per (tile, wave) tells the wave whose partial arrives
+    // LAST, and that wave adds all KS partials in the fixed order 0 .. KS-1 (its own included, read back like the others:
+    // the same bits whoever is last) and runs the epilogue.  No wave ever waits for another workgroup.
+    // Visibility between workgroups (per-XCD L2s, per-CU L1s: MI355X_MICROARCH.md, valid hand-off forms): every partial is
+    // stored write-through (sc1) and drained (vmcnt 0) by the wave that then adds to the counter (agent-scope atomic); the
+    // last wave reads every partial with sc1 loads.  No release / acquire fence (an agent-scope release writes back the whole
+    // L2: measured +30 us per split launch).
+    if (KS > 1) {
+      typedef __attribute__((ext_vector_type(4))) float f32x4;
+      const int tile_id = tile / KS;                                     // (n, ty, tx, ct): the same for the KS workgroups of a tile
+      const int ntile = total_tiles / KS;
+      constexpr int WAVE_BYTES = MW * NW * 16 * 64 * 4;
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)a.kpart, 0, KS * ntile * C::NCONS * WAVE_BYTES, 0x00020000);
+      const int mine = ((ks * ntile + tile_id) * C::NCONS + cw) * WAVE_BYTES + lane * 16;
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            // (whole-vector bit casts only: __builtin_bit_cast of a vector ELEMENT reads the vector's first element whatever the
+            // index -- hipcc, ROCm 7.2)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){acc[m][j][4 * q], acc[m][j][4 * q + 1], acc[m][j][4 * q + 2], acc[m][j][4 * q + 3]}),
+                                                   prs, mine + ((m * NW + j) * 4 + q) * 1024, 0, 16 /* sc1 */);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(a.kcnt + tile_id * C::NCONS + cw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old != (unsigned)(KS - 1)) { WS_STAMP(2) continue; }         // another workgroup's wave finishes this part of the tile
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           // (compiler only: the loads stay behind the add)
+      if (lane == 0) __hip_atomic_store(a.kcnt + tile_id * C::NCONS + cw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      // two partials in flight (KS is even or 1 x odd ... the plan only makes even splits or 3: handled by the tail)
+      auto fetch = [&](f32x4 (&pv)[MW * NW * 4], int k2) {
+        const int src = ((k2 * ntile + tile_id) * C::NCONS + cw) * WAVE_BYTES + lane * 16;
+#pragma unroll
+        for (int t = 0; t < MW * NW * 4; ++t) pv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, src + t * 1024, 0, 16 /* sc1 */));
+      };
+      auto add = [&](const f32x4 (&pv)[MW * NW * 4], bool first) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+          for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = first ? pv[(m * NW + j) * 4 + q][i] : acc[m][j][4 * q + i] + pv[(m * NW + j) * 4 + q][i];
+      };
+      f32x4 pa[MW * NW * 4], pb[MW * NW * 4];
+      fetch(pa, 0);
+      for (int k2 = 0; k2 < KS; k2 += 2) {                               // the order of the additions stays 0, 1, 2, ...
+        if (k2 + 1 < KS) fetch(pb, k2 + 1);
+        if (k2 == 0) add(pa, true); else add(pa, false);
+        if (k2 + 2 < KS) fetch(pa, k2 + 2);
+        if (k2 + 1 < KS) add(pb, false);
+      }
+    }
 #pragma unroll
     for (int m2 = 0; m2 < MW / 2; ++m2)
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        const bool give = C::HANDOFF && a.nchunks >= 2 && (MW == 4 ? m2 == 1 : j == 1);      // this pair goes to producer wave cw
+        const bool give = handoff && (MW == 4 ? m2 == 1 : j == 1);      // this pair goes to producer wave cw
         if (give) {
           char* st = smem + (2 * C::BUF_BYTES + 2 * C::LS_BYTES + 2 * C::PATCH_BYTES) + cw * C::STG_WAVE + lane * 16;
 #pragma unroll
@@ -1159,7 +1229,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       }
     WS_STAMP(2)
   }
-  if (C::HANDOFF && a.nchunks >= 2) lds_barrier();        // the last handed-over pair is in LDS
+  if (handoff) lds_barrier();        // the last handed-over pair is in LDS
 #ifdef UNETPP_WS_DBG
   if (a.stamps && cw == 0 && lane == 0)
 #pragma unroll

@@ -328,15 +328,21 @@ struct UpsumArgs {
 // Per tap the <= 11 x 19 low-res records (128 B each) the tile can touch arrive by LDS-DMA, so every Y record is fetched
 // once per tile and tap and the 36 corner reads per output come from LDS, not from the vector cache.  One staging
 // buffer and <= 128 VGPRs: four workgroups share a CU and cover each other's DMA round trips.
-struct UpsumCfg {
-  static constexpr int TH = 16, TW = 32, RH = TH / 2 + 3, RW = TW / 2 + 3, RECS = RH * RW;
+template <int TH_>
+struct UpsumCfgT {
+  static constexpr int TH = TH_, TW = 32, RH = TH / 2 + 3, RW = TW / 2 + 3, RECS = RH * RW;
   static constexpr int PIECES = (RECS * 128 + 1023) / 1024, BUF_BYTES = PIECES * 1024;
   static constexpr int YTAB_BYTES = (TH + 2) * 16, LDS_BYTES = BUF_BYTES + YTAB_BYTES;     // one buffer: four workgroups per CU overlap each other
   static constexpr int ITERS = (PIECES + 3) / 4;
 };
+typedef UpsumCfgT<16> UpsumCfg;
 
-__global__ __launch_bounds__(256, 4) void upsum_kernel(UpsumArgs a) {
-  using C = UpsumCfg;
+// TH = rows of a tile: 16, or 4 for grids that would leave most CUs idle (small batches: a workgroup's 16 rows x 9 taps of corner
+// reads and FMAs are ~20 us of dependent work however few workgroups there are).  TB = taps staged per round (1; 3 was tried for
+// the small grids and changed nothing: the launch waits for the workgroups' own arithmetic, not for their DMA round trips).
+template <int TB, int TH_ = 16>
+__global__ __launch_bounds__(256, TB == 1 ? 4 : 1) void upsum_kernel(UpsumArgs a) {
+  using C = UpsumCfgT<TH_>;
   typedef __attribute__((ext_vector_type(4))) float f32x4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int H = a.H, W = a.W, h = H >> 1, w = W >> 1;
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256, 4) void upsum_kernel(UpsumArgs a) {
   }
   // per shifted row (the same for every thread): corner row offsets + weights, kept in LDS
   struct YRow { int o0, o1; float l0, l1; };
-  YRow* ytab = (YRow*)(smem + C::BUF_BYTES);
+  YRow* ytab = (YRow*)(smem + TB * C::BUF_BYTES);
   if (tid < C::TH + 2) {
     const int yy = y0 + tid - 1;
     const bool in = yy >= 0 && yy < H;
@@ -408,12 +414,16 @@ __global__ __launch_bounds__(256, 4) void upsum_kernel(UpsumArgs a) {
 #pragma unroll
   for (int r = 0; r < C::TH; ++r) sum[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tap = 0; tap < 9; ++tap) {
-    __syncthreads();                                                // everyone has left the buffer (first trip: ytab visible)
-    stage(tap, 0);
+  for (int tap0 = 0; tap0 < 9; tap0 += TB) {
+    __syncthreads();                                                // everyone has left the buffers (first trip: ytab visible)
+#pragma unroll
+    for (int t = 0; t < TB; ++t) stage(tap0 + t, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                                // tap's records landed
-    const char* reg = smem;
+    __syncthreads();                                                // the taps' records landed
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+    const int tap = tap0 + t;
+    const char* reg = smem + t * C::BUF_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
     for (int r = 0; r < C::TH; ++r) {
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(256, 4) void upsum_kernel(UpsumArgs a) {
         const float t0 = fmaf(xl1[dx], c01[e], xl0[dx] * c00[e]), t1 = fmaf(xl1[dx], c11[e], xl0[dx] * c10[e]);   // x inside each row first
         sum[r][e] += fmaf(yr.l1, t1, yr.l0 * t0);
       }
+    }
     }
   }
   const int x = x0 + col;

@@ -48,8 +48,9 @@ const int SB[4] = {64, 128, 256, 512};        // SimpleUNet widths, simple_unet.
 struct Tensor {
   std::string name;
   size_t off = 0;   // byte offset inside one activation slot
-  int C = 0;
+  int C = 0;        // channels of an activation tensor; 0 = raw bytes (fp32 side tensors, split-K buffers)
   int lvl = 0;
+  bool virt = false;   // named in the graph but never written (fused away): no storage
 };
 
 struct ConvLayer {
@@ -143,6 +144,8 @@ struct unetpp_engine {
   bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
   bool use_ws = true;             // exact-mode convs in the wave-specialised kernel (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
+  int ksplit_max = 16, ksplit_min_chunks = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
+  int t_kpart = -1, t_kcnt = -1;  // per slot: partial sums and arrival counters of the split tiles
 };
 
 namespace {
@@ -216,7 +219,7 @@ size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
 }
 
 // ---- conv dispatch ---------------------------------------------------------------------------
-struct LaunchCtx { int device; int num_cus; };   // per engine: one process may drive engines on several devices
+struct LaunchCtx { int device; int num_cus; int ksplit_max = 1, ksplit_min_chunks = 4; };   // per engine: one process may drive engines on several devices
 
 // The conv kernels take more dynamic LDS than the 64 KiB default: raise the function's limit to the whole 160 KiB
 // once per (device, kernel).  The attribute is process-wide state of the HIP runtime and engines may be driven
@@ -252,7 +255,18 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   using C = WsCfg<P, UPF, C0F, NW, MW, X8>;
   a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
   const int lds = C::LDS_BYTES + a.Cout * 8 + (HEAD ? ((a.head_C * 33 * 4 + 15) / 16) * 16 : 0);
-  const int total = a.N * a.tiles_x * a.tiles_y * a.nct;
+  // Split-K plan (small batches): a layer with fewer tiles than a quarter of the CUs shares each tile's K-chunks among
+  // `ksplit` workgroups -- the largest divisor of the chunk count that still leaves every workgroup four chunks and fits
+  // the chip (measured at batch 1, 512x512: levels 3-4 gain 10-35 us per layer; two-way splits and two-chunk shares gain nothing:
+  // a split launch costs its partials' round trip, ~10 us).
+  // The plan depends on (batch, H, W) only; results of different plans differ in summation order (1e-7-class).
+  const int tiles = a.N * a.tiles_x * a.tiles_y * a.nct;
+  int ks = 1;
+  if (!UPF && !C0F && !HEAD && a.kpart && a.kcnt && cx.ksplit_max > 1 && tiles * 4 <= cx.num_cus)
+    for (int d = 2; d <= cx.ksplit_max && tiles * d <= cx.num_cus && a.nchunks / d >= cx.ksplit_min_chunks; ++d)
+      if (a.nchunks % d == 0) ks = d;
+  a.ksplit = ks;
+  const int total = tiles * ks;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
   auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW, X8>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
@@ -388,12 +402,12 @@ struct Builder {
   unetpp_engine* e;
   size_t act = 0;     // bytes of one activation slot so far
   size_t off = 0;     // floats of the blob payload so far
-  int tensor(const std::string& name, int C, int lvl) {
+  int tensor(const std::string& name, int C, int lvl, bool virt = false) {
     Tensor t;
-    t.name = name; t.C = C; t.lvl = lvl; t.off = act;
+    t.name = name; t.C = C; t.lvl = lvl; t.off = act; t.virt = virt;
     const unetpp_config& c = e->cfg;
     size_t px = (size_t)e->mb * (c.max_h >> lvl) * (c.max_w >> lvl);
-    act += align_up(px * e->P * C * sizeof(half_t), 256);
+    if (!virt) act += align_up(px * e->P * C * sizeof(half_t), 256);
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
   }
@@ -443,12 +457,12 @@ void build_nested(unetpp_engine* e, Builder& b) {
   // no x0_0a tensor): conv3x3_ws.h, C0F.  UNETPP_NO_C0F=1 keeps the three launches (A/B measurements).
   const bool c0f = e->P == 2 && e->use_ws && !getenv("UNETPP_NO_C0F");
   if (!c0f) { Op cv; cv.kind = OP_CONVERT; e->ops.push_back(cv); }
-  e->t_in8 = b.tensor("in8", 8, 0);
+  e->t_in8 = b.tensor("in8", 8, 0, c0f);            // fused first block: neither the fp16 input copy nor x0_0a exists
   int x[5], xa[5], pooled[4], up[4], d[4], da[4];
   for (int l = 0; l < 5; ++l) {
     char nm[32];
     snprintf(nm, sizeof nm, "x%d_0", l);
-    xa[l] = b.tensor(std::string(nm) + "a", NB[l], l);
+    xa[l] = b.tensor(std::string(nm) + "a", NB[l], l, c0f && l == 0);
     x[l] = b.tensor(nm, NB[l], l);
     if (l < 4) pooled[l] = b.tensor(std::string(nm) + "p", NB[l], l + 1);
     snprintf(nm, sizeof nm, "conv%d_0", l);
@@ -466,7 +480,7 @@ void build_nested(unetpp_engine* e, Builder& b) {
     // separate kernel (A/B measurements).
     // (EXACT8: every level that does not take the low-resolution GEMM below interpolates in its loader -- the separate
     // upsample kernel and the two-source loader do not know the 8-bit planes)
-    const bool upf = e->x8 || (!getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && !getenv("UNETPP_NO_UPF1"))));
+    const bool upf = e->x8 || (!getenv("UNETPP_NO_UPF") && (l == 0 || (l == 1 && e->P == 2 && e->ws64 && NB[1] <= e->ws_max_cout && !getenv("UNETPP_NO_UPF1"))));      // level 1: only the wave-specialised kernel has the fused loader for Cout = 64 (layer_uses_ws)
     // Levels 2-3 (exact mode): the up channels are multiplied at LOW resolution and interpolated afterwards
     // (tapmm_ws.h: half the flops of the layer); UNETPP_TAPMM=levels overrides, e.g. "" (off) or "123".
     const char* tl = getenv("UNETPP_TAPMM");
@@ -615,8 +629,19 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
   const int P = e->P;
 
+  if (const char* k = getenv("UNETPP_KSPLIT")) {
+    e->ksplit_max = std::max(1, atoi(k));
+    if (const char* c = strchr(k, ',')) e->ksplit_min_chunks = std::max(1, atoi(c + 1));
+  }
   Builder b{e};
   if (cfg->arch == UNETPP_ARCH_NESTED) build_nested(e, b); else build_simple(e, b);
+  if (e->P == 2 && e->use_ws && e->ksplit_max > 1) {
+    // at most num_cus workgroups take part in a split launch, each with 4 consumer waves x 16 KB of raw accumulators
+    e->t_kpart = (int)e->tensors.size();
+    { Tensor t; t.name = "ksplit.partials"; t.off = b.act; e->tensors.push_back(t); b.act += align_up((size_t)e->num_cus * 4 * 16384, 256); }
+    e->t_kcnt = (int)e->tensors.size();
+    { Tensor t; t.name = "ksplit.counters"; t.off = b.act; e->tensors.push_back(t); b.act += align_up((size_t)e->num_cus * 4 * sizeof(unsigned), 256); }
+  }
   e->blob_floats = b.off;
   if (b.off != blob_payload_floats(cfg->arch, cfg->num_classes, 3, &e->n_blob_layers)) {
     delete e;
@@ -663,6 +688,9 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     return fail(nullptr, UNETPP_E_HIP, "hipMalloc(%zu bytes): %s", total, m.c_str());
   }
   e->arena_bytes = total;
+  if (e->t_kcnt >= 0)
+    for (int i = 0; i < e->nstreams; ++i)
+      (void)hipMemset(e->arena + (size_t)i * e->act_bytes + e->tensors[e->t_kcnt].off, 0, (size_t)e->num_cus * 4 * sizeof(unsigned));
   e->d_status = (unsigned*)(e->arena + status_off);
   e->c1w = (half_t*)(e->arena + c1w_off);
   e->blob = (float*)(e->arena + blob_off);
@@ -887,6 +915,8 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.N = nb; a.H = H; a.W = W; a.Cout = L.cout;
         a.status = e->d_status;
         a.zinit = L.zt >= 0 ? (const float*)tp(L.zt) : nullptr;
+        if (e->t_kpart >= 0) { a.kpart = (float*)tp(e->t_kpart); a.kcnt = (unsigned*)tp(e->t_kcnt); }
+        a.ksplit = 1;
         if (L.c0f) {     // the first block reads the caller's tensor itself
           const ConvLayer& L1 = e->convs[e->c0f_conv1];
           a.raw_in = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
@@ -933,7 +963,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2, tf(e->x8));
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
-          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
+          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus, e->ksplit_max, e->ksplit_min_chunks}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
 #ifdef UNETPP_WS_DBG
@@ -977,12 +1007,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         } else {
           UpsumArgs u{};
           u.y = (const float*)tp(L.y_t); u.z = (float*)tp(L.zt); u.N = nb; u.H = H; u.W = W; u.Cout = L.cout;
-          const unsigned blocks = (unsigned)(((W + UpsumCfg::TW - 1) / UpsumCfg::TW) * ((H + UpsumCfg::TH - 1) / UpsumCfg::TH) * (L.cout / 32) * nb);
+          unsigned blocks = (unsigned)(((W + UpsumCfg::TW - 1) / UpsumCfg::TW) * ((H + UpsumCfg::TH - 1) / UpsumCfg::TH) * (L.cout / 32) * nb);
           const double px = (double)nb * H * W;
           char lbl[96];
-          snprintf(lbl, sizeof lbl, "%s.up-sum|upsum_kernel", L.name.c_str());
+          const bool small = blocks <= (unsigned)e->num_cus;      // too few 16-row tiles for the chip: 4-row tiles
+          if (small) blocks = (unsigned)(((W + 31) / 32) * ((H + 3) / 4) * (L.cout / 32) * nb);
+          snprintf(lbl, sizeof lbl, "%s.up-sum|upsum_kernel<1, %d>", L.name.c_str(), small ? 4 : 16);
           Lx.run(lbl, px * L.cout * 9 * 8.0, px / 4 * 9 * L.cout * 4.0 + px * L.cout * 4.0, [&] {
-            hipLaunchKernelGGL(upsum_kernel, dim3(blocks), dim3(256), UpsumCfg::LDS_BYTES, s, u);
+            if (small) hipLaunchKernelGGL((upsum_kernel<1, 4>), dim3(blocks), dim3(256), UpsumCfgT<4>::LDS_BYTES, s, u);
+            else hipLaunchKernelGGL((upsum_kernel<1, 16>), dim3(blocks), dim3(256), UpsumCfg::LDS_BYTES, s, u);
             return hipSuccess;
           });
         }
@@ -1204,6 +1237,8 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   for (size_t i = 0; i < e->tensors.size(); ++i)
     if (e->tensors[i].name == name) { t = &e->tensors[i]; tid = (int)i; }
   if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
+  if (t->virt) return fail(e, UNETPP_E_STATE, "'%s' is never materialised on this engine (fused into its consumer)", name);
+  if (t->C == 0) return fail(e, UNETPP_E_STATE, "'%s' is not an activation tensor (raw fp32 / bookkeeping buffer)", name);
   if (e->cfg.arch == UNETPP_ARCH_NESTED && tid == e->t_head_in && !e->keep_all)
     return fail(e, UNETPP_E_STATE, "x0_4 is not materialised (head fused): call unetpp_debug_keep_intermediates(e, 1) before forward");
   ENTER_DEVICE(e);
