@@ -238,13 +238,20 @@ def test_config5_1024_exact_vs_oracle_and_batch_invariance(torch_cuda, syn, orac
     assert err < 3e-5 and unexplained == 0 and flips <= 8
 
 
-def test_config4_7class_448x800_batch_properties(torch_cuda, syn):
-    """BASELINE config 4 shape at batch 32 (exact): batch-row invariance and u8-vs-f32 input agreement."""
+def test_config4_7class_448x800_batch_properties(torch_cuda, syn, oracle):
+    """BASELINE config 4 shape at batch 32 (exact): frames 0 and 31 of the batch against the oracle on the host,
+    batch-row invariance and u8-vs-f32 input agreement."""
     torch = torch_cuda
     frames = syn.make_frames_u8(32, 448, 800, "smooth", 5)
-    model, _ = make_model(7, False, 0, "exact", syn, 32, (448, 800))
+    model, sd = make_model(7, False, 0, "exact", syn, 32, (448, 800))
     fu8 = torch.from_numpy(frames).cuda()
-    mask = model.segment(fu8)
+    mask, logits = model.segment(fu8, return_logits=True)
+    torch.cuda.synchronize()
+    ref = oracle.torch_forward(sd, syn.frames_to_chw_f32(frames[[0, 31]]))
+    ref_mask, _, _ = oracle.masks_from_logits(ref)
+    err, flips, unexplained = report(logits[[0, 31]].cpu().numpy(), mask[[0, 31]].cpu().numpy(), ref, ref_mask, oracle)
+    print(f"config 4, B=32, frames 0 and 31 vs oracle: max|dlogit|={err:.3e} flips={flips}/{ref_mask.size}")
+    assert err < 3e-5 and err < LOGIT_TOL and unexplained == 0 and flips <= 8
     m5 = model.segment(fu8[4:6])            # (two frames: like 32, too many tiles for a split-K plan -- equal plans, equal bits)
     mf = model.segment(torch.from_numpy(syn.frames_to_chw_f32(frames[30:32])).cuda())
     torch.cuda.synchronize()

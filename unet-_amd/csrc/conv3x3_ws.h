@@ -249,12 +249,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
 
   // per-channel (scale, bias) of the layer and the head weights, staged once per workgroup (read by the consumers)
+  // (by the CONSUMER waves only, which have nothing else to do until the first chunk has landed: the producers go straight
+  // to their first DMA instead of waiting for these loads; the first chunk's barrier publishes the table -- a launch of one
+  // tile per CU, i.e. a small batch, is a chain of such latencies)
   float2* sb_lds = (float2*)(smem + C::LDS_BYTES);
-  for (int i = tid; i < a.Cout; i += NT) sb_lds[i] = make_float2(a.scale[i], a.bias[i]);
   float* head_lds = (float*)(smem + C::LDS_BYTES + a.Cout * 8);
-  if (HEAD) {
-    for (int i = tid; i < a.head_C * 32; i += NT) head_lds[i] = a.head_w[i];
-    for (int i = tid; i < a.head_C; i += NT) head_lds[a.head_C * 32 + i] = a.head_b[i];
+  if (wave < C::NCONS) {
+    for (int i = tid; i < a.Cout; i += C::NCONS * 64) sb_lds[i] = make_float2(a.scale[i], a.bias[i]);
+    if (HEAD) {
+      for (int i = tid; i < a.head_C * 32; i += C::NCONS * 64) head_lds[i] = a.head_w[i];
+      for (int i = tid; i < a.head_C; i += C::NCONS * 64) head_lds[a.head_C * 32 + i] = a.head_b[i];
+    }
   }
 
   // tile order as in conv3x3_bias_relu_kernel: an XCD (workgroups b, b+8, ...) walks a contiguous run of tiles
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     patch_store(0, pv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __syncthreads();                                       // sb_lds / head_lds (C0F: slabs, first patch) visible
+  if (C0F) __syncthreads();                              // C0F: slabs, zero words and the first patch visible to all producer waves
 
 #ifdef UNETPP_WS_DBG
 #define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; }
