@@ -85,6 +85,17 @@ def conv(x, w, mode):
             return e4(t * s) / s
         acc = c(xh, wsh) + c(e5(xl), qw(wsh)) + c(e5(x), qw(wsl))
         return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
+    if mode == "x8":
+        # precision 'exact8' as built (csrc/conv3x3_mfma.h split_pack4_x8, aux_kernels.h weight_pack_x8_kernel):
+        #   lo8 = e5m2(2^8 xl), x8 = e5m2(2^-3 x), wh8 = e4m3(2^-6 ws), wl8 = e4m3(2^5 (ws - fp16(ws))), block scales 2^6 * 2^-8
+        e5 = lambda t: t.to(torch.float32).to(torch.float8_e5m2).to(torch.float64)
+        e4 = lambda t: t.to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        mx = w.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
+        k = 14 - torch.floor(torch.log2(mx)) - 1
+        ws = w * 2.0 ** k
+        wsh = ws.to(torch.float16).to(torch.float64)
+        acc = c(xh, wsh) + (c(e5(xl * 256.0), e4(ws / 64.0)) + c(e5(x / 8.0), e4((ws - wsh) * 32.0))) * 0.25
+        return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
     if mode == "bf8":
         return c(xh, wh) + c(q_e4m3(xl, 2), q_e4m3(w, 2)) + c(q_e4m3(x, 2), q_e4m3(wl, 2))
     raise ValueError(mode)
@@ -97,7 +108,10 @@ def forward(layers, head, x, mode):
             # per-output-channel power-of-two scaling as the engine does (keeps fp16 weights in range)
             t = conv(t, w, mode) + b[None, :, None, None]
             t = torch.relu(t)
-            if mode != "ref":      # activations are stored as fp16 hi + lo
+            if mode == "x8":       # stored as fp16 hi + e5m2(2^8 lo): what the next layer (conv, upsample, pool) reads back
+                h = t.to(torch.float16).to(torch.float64)
+                t = h + ((t - h) * 256.0).to(torch.float32).to(torch.float8_e5m2).to(torch.float64) / 256.0
+            elif mode != "ref":    # activations are stored as fp16 hi + lo
                 h, l = split16(t)
                 t = h + l
         return t
