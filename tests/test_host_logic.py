@@ -131,3 +131,19 @@ def test_fused_upsample_index_claims(n_out):
         assert i1[lo:hi + 1].max() - int(np.float32(s * np.float32(lo))) + 1 <= 11
     odd = np.arange(1, n_out - 1, 2)
     assert np.array_equal(i0[odd], i0[odd + 1]) and np.array_equal(i1[odd], i1[odd + 1])
+
+
+def test_precision_codes_match_the_header():
+    """include/unetpp.h's UNETPP_PREC_* enum and the Python binding's table are the same numbers."""
+    import re
+    from conftest import ROOT
+    from unet_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "unetpp.h")).read()
+    m = re.search(r"enum \{ UNETPP_PREC_EXACT = (\d+), UNETPP_PREC_FAST = (\d+), UNETPP_PREC_EXACT8 = (\d+) \};", hdr)
+    assert m, "precision enum not found in include/unetpp.h"
+    assert (_lib.PRECISIONS["exact"], _lib.PRECISIONS["fast"], _lib.PRECISIONS["exact8"]) == tuple(int(g) for g in m.groups())
+    from unet_amd.nested_unet import NestedUNet
+    import pytest
+    with pytest.raises(ValueError):
+        NestedUNet(3, precision="exact16")
+    assert NestedUNet(3, precision="exact8").precision == "exact8"      # construction needs no device

@@ -1042,6 +1042,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           }
         };
         auto main_step = [&](const BM& b, const half8 (&hf)[R], int dy, bool first) {
+#ifdef UNETPP_WS_DBG
+          if (a.dbg & 4) return;
+#endif
           const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int m = 0; m < MW; ++m)
@@ -1050,6 +1053,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
               acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.w[j], hf[m + dy], first ? zero : acc[m][j], 0, 0, 0);
         };
         auto cross_step = [&](const BX& b, const int8v (&x)[R], int r0) {
+#ifdef UNETPP_WS_DBG
+          if (a.dbg & (4 | 65536)) return;      // 65536: the cross terms only (how much of a chunk they are)
+#endif
 #pragma unroll
           for (int m = 0; m < MW; ++m)
 #pragma unroll
