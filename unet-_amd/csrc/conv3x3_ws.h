@@ -1193,29 +1193,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
       if (old != (unsigned)(KS - 1)) { WS_STAMP(2) continue; }         // another workgroup's wave finishes this part of the tile
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");           // (compiler only: the loads stay behind the add)
       if (lane == 0) __hip_atomic_store(a.kcnt + tile_id * C::NCONS + cw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      // two partials in flight (KS is even or 1 x odd ... the plan only makes even splits or 3: handled by the tail)
-      auto fetch = [&](f32x4 (&pv)[MW * NW * 4], int k2) {
-        const int src = ((k2 * ntile + tile_id) * C::NCONS + cw) * WAVE_BYTES + lane * 16;
+      // Units of half a partial (8 of its 16 KB-pieces, 32 registers), two units in flight; every accumulator element still
+      // receives its partials in the order 0, 1, 2, ...
+      constexpr int HALF = MW * NW * 2;
+      auto fetch = [&](f32x4 (&pv)[HALF], int u) {
+        const int src = (((u >> 1) * ntile + tile_id) * C::NCONS + cw) * WAVE_BYTES + lane * 16 + (u & 1) * HALF * 1024;
 #pragma unroll
-        for (int t = 0; t < MW * NW * 4; ++t) pv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, src + t * 1024, 0, 16 /* sc1 */));
+        for (int t = 0; t < HALF; ++t) pv[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, src + t * 1024, 0, 16 /* sc1 */));
       };
-      auto add = [&](const f32x4 (&pv)[MW * NW * 4], bool first) {
+      auto add = [&](const f32x4 (&pv)[HALF], int u) {
 #pragma unroll
         for (int m = 0; m < MW; ++m)
 #pragma unroll
           for (int j = 0; j < NW; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+              const int t = (m * NW + j) * 4 + q;
+              if ((t >= HALF) != ((u & 1) != 0)) continue;            // the other half of the partial
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = first ? pv[(m * NW + j) * 4 + q][i] : acc[m][j][4 * q + i] + pv[(m * NW + j) * 4 + q][i];
+              for (int i = 0; i < 4; ++i) acc[m][j][4 * q + i] = u < 2 ? pv[t % HALF][i] : acc[m][j][4 * q + i] + pv[t % HALF][i];
+            }
       };
-      f32x4 pa[MW * NW * 4], pb[MW * NW * 4];
+      f32x4 pa[HALF], pb[HALF];
       fetch(pa, 0);
-      for (int k2 = 0; k2 < KS; k2 += 2) {                               // the order of the additions stays 0, 1, 2, ...
-        if (k2 + 1 < KS) fetch(pb, k2 + 1);
-        if (k2 == 0) add(pa, true); else add(pa, false);
-        if (k2 + 2 < KS) fetch(pa, k2 + 2);
-        if (k2 + 1 < KS) add(pb, false);
+      for (int u = 0; u < 2 * KS; u += 2) {
+        fetch(pb, u + 1);
+        add(pa, u);
+        if (u + 2 < 2 * KS) fetch(pa, u + 2);
+        add(pb, u + 1);
       }
     }
 #pragma unroll
