@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     // interpolation item r of this lane: block (by, bx) x channel quad q
     int up_o00[UPR], up_o01[UPR], up_o10[UPR];          // staging offsets of the corners (ra,ca), (ra,cb), (rb,ca)
     float up_wx[UPR][4], up_wy[UPR][4];                  // {lx0, lx1} of the block's two columns, {ly0, ly1} of its two rows
-    int up_dst[UPR];                                     // halo-image offset of the block's first pixel, -1 = no item
+    int up_st[UPR][4];                                   // halo-image byte offsets of the block's four pixels (2 ky + kx), [0] = -1: no item
     // A corner is only ever used as hi + lo, so the two 8-byte reads of a record may come in either order: the second
     // 16 lanes of every 32-lane read group (blocks 4..7 of eight neighbouring blocks) fetch lo first.  With 64-byte
     // records the first read then touches banks [16 rx, 16 rx + 8) in blocks 0..3 and [16 rx + 8, 16 rx + 16) in
@@ -626,14 +626,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         const int i = pw * 64 + lane + r * (C::NPROD * 64);
         const int q = i & 3, blk = i >> 2;
         const int by = blk / C::BLK_X, bx = blk - by * C::BLK_X;
-        const int hp = (2 * by) * HALO_W + 2 * bx;
-        // first pixel of the block; its right neighbour is hp + 1, the row below hp + HALO_W (computed at the store)
-        up_dst[r] = i < C::UP_ITEMS ? hp * 4 + q : -1;
+        const int hp0 = (2 * by) * HALO_W + 2 * bx;       // first pixel of the block; right neighbour hp0 + 1, the row below hp0 + HALO_W
+        // byte offset of channel quad q of halo pixel hp, plane 0: (hp / PPP) * 1024 + ((q >> 1) * PPP + hp % PPP) * 16 + (q & 1) * 8.
+        // Lanes of the second channel octet (q >= 2) take the block's two columns in the opposite order (see setup_tile).
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          const int hp = hp0 + (px >> 1) * HALO_W + ((px & 1) ^ ((q >> 1) & 1));
+          up_st[r][px] = (hp / PPP) * 1024 + ((q >> 1) * PPP + hp % PPP) * 16 + (q & 1) * 8;
+        }
+        if (i >= C::UP_ITEMS) up_st[r][0] = -1;
       }
     }
-    auto halo_dst = [&](int hp, int q) {                 // byte offset of channel quad q of halo pixel hp, plane 0
-      return (hp / PPP) * 1024 + ((q >> 1) * PPP + hp % PPP) * 16 + (q & 1) * 8;
-    };
 
     auto setup_tile = [&](int n, int y0, int x0) {
       if (y0 >= 1 && y0 + TH < H && x0 >= 1 && x0 + TW < W) {          // halo rows y0-1 .. y0+TH, columns x0-1 .. x0+TW
@@ -737,14 +740,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           for (int k = 0; k < 4; ++k) {
             // corner value = hi + lo, exact in fp32; one mixed-precision FMA reads both halves out of the packed words
             if (X8) {
-              // value = hi + 2^-8 lo8: the low-res tensor is what the previous layer stored (hi, lo8); word 0 of the second
-              // read holds the four lo8 bytes of this channel quad
-              const float lo = e == 0 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 0)
-                             : e == 1 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 1)
-                             : e == 2 ? __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 2)
-                                      : __builtin_amdgcn_cvt_scalef32_f32_bf8((int)lq[r][k][0], X8_LO_MUL, 3);
-              if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo));
-              else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo));
+              // value = hi + 2^-8 lo8: the low-res tensor is what the previous layer stored (hi, lo8); word 0 of the second read
+              // holds the four lo8 bytes of this channel quad.  One v_cvt_scalef32_pk_f16_bf8 turns a byte pair into a packed
+              // fp16 pair (exact: three significant bits, 2^-24 the smallest), then the same mixed-precision FMA as in `exact`.
+              const unsigned lo16 = __builtin_bit_cast(unsigned, (e >> 1) ? __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lq[r][k][0], X8_LO_MUL, true)
+                                                                        : __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lq[r][k][0], X8_LO_MUL, false));
+              if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo16));
+              else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lo16));
             } else if (P == 2) {
               if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
               else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(cc[k]) : "v"(hq[r][k][e >> 1]), "v"(lq[r][k][e >> 1]));
@@ -766,8 +768,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
         if (a.dbg & 64) { if (v[0][0] == 12345.f && v[3][3] == 7.f && v[1][2] == 3.f && v[2][1] == 9.f) a.status[1] = 1; continue; }
 #endif
-        if (up_dst[r] >= 0) {
-          const int hp0 = up_dst[r] >> 2, q = up_dst[r] & 3;
+        if (up_st[r][0] >= 0) {
 #pragma unroll
           for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
                 h0 = __builtin_bit_cast(unsigned, a0); h1 = __builtin_bit_cast(unsigned, a1);
               }
               const u32x2 oh = {h0, h1}, ol = {l0, l1};
-              char* dst = smem + halo_off + halo_dst(hp0 + ky * HALO_W + (kx ^ ((q >> 1) & 1)), q);
+              char* dst = smem + halo_off + up_st[r][px];
               *(u32x2*)dst = oh;
               if (P == 2) *(u32x2*)(dst + KG * PPP * 16) = ol;
             }
