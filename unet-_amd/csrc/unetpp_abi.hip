@@ -146,6 +146,7 @@ struct unetpp_engine {
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
   int ksplit_max = 16, ksplit_min_chunks = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
   int t_kpart = -1, t_kcnt = -1;  // per slot: partial sums and arrival counters of the split tiles
+  bool kcnt_dirty = false;        // a forward returned early: its split launches may have left counters behind
 };
 
 namespace {
@@ -873,6 +874,13 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     for (int i = 0; i < e->nstreams; ++i) HIP_TRY(e, hipStreamWaitEvent(e->streams[i], e->ev_start, 0));
   }
   e->last_b = batch; e->last_h = h; e->last_w = w;
+  // The last arriver of every split tile puts its counter back to zero, so a completed forward leaves them clean; after a
+  // forward that failed half-way they are cleared here (stream-ordered, before the first launch).
+  if (e->t_kcnt >= 0 && e->kcnt_dirty)
+    for (int i = 0; i < e->nstreams; ++i)
+      HIP_TRY(e, hipMemsetAsync(e->arena + (size_t)i * e->act_bytes + e->tensors[e->t_kcnt].off, 0, (size_t)e->num_cus * 4 * sizeof(unsigned),
+                                multi ? e->streams[i] : user_stream));
+  e->kcnt_dirty = true;
   Launcher Lx{e, s};
   int pass = 0;
   e->prof_prev_ev = -1;     // other work may sit between two forwards: start a fresh event chain
@@ -1072,6 +1080,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     if (Lx.rc) return Lx.rc;
   }
   HIP_TRY(e, join.run());
+  e->kcnt_dirty = Lx.rc != UNETPP_OK;
   return Lx.rc;
 }
 
