@@ -85,9 +85,11 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, const float* __r
 //             wh8 = e4m3(2^-6 ws)   (ws = w 2^k, max |ws| in [2^13, 2^14): at most 256)
 //             wl8 = e4m3(2^5 (ws - fp16(ws)))   (|ws - fp16(ws)| <= 4: at most 128)
 //          so that with the block scales 2^6 (weights) and 2^-8 (activations: lo8 = 2^8 lo, x8 = 2^-3 x) the instruction adds
-//          ws * lo + (ws - fp16(ws)) * x.   Pairs (taps as dy * 3 + dx): (0,1) (3,4) (6,7) (2,5) (8,-): the consumers' order.
+//          ws * lo + (ws - fp16(ws)) * x.   Pairs (taps as dy * 3 + dx): (0,1) (3,4) (6,7) (2,5) (-,8): the consumers' order.
+// pair9: the fifth pair of an ODD chunk holds tap 8 of the chunk before it and tap 8 of its own (the consumers keep the even
+// chunk's operand in registers until then); the fifth pair of an even chunk is not used.
 __global__ void weight_pack_x8_kernel(const float* __restrict__ w, const float* __restrict__ mult, int Cin, int Cout, int BN, int nchunks,
-                                      char* __restrict__ out, long long units) {
+                                      char* __restrict__ out, long long units, int pair9) {
   const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   const int per = 38 * BN;
@@ -112,7 +114,12 @@ __global__ void weight_pack_x8_kernel(const float* __restrict__ w, const float* 
     return;
   }
   const int h = (r / BN) & 1, half = (r / (2 * BN)) & 1, pair = r / (4 * BN);
-  const int tap = pair < 3 ? pair * 3 + half : (pair == 3 ? (half ? 5 : 2) : (half ? -1 : 8));
+  // pair 4: bytes 16-31 = tap 8 of this chunk; bytes 0-15 = tap 8 of the chunk before (pair9, odd chunks) or nothing
+  int tap = pair < 3 ? pair * 3 + half : (pair == 3 ? (half ? 5 : 2) : (half ? 8 : -1));
+  int cc = c;                     // chunk whose channels this 16-byte unit holds
+  if (pair9 && pair == 4) {
+    if (c & 1) { tap = 8; cc = half ? c : c - 1; } else tap = -1;
+  }
   unsigned wd[4] = {0u, 0u, 0u, 0u};
   if (tap >= 0) {
 #pragma unroll
@@ -120,7 +127,7 @@ __global__ void weight_pack_x8_kernel(const float* __restrict__ w, const float* 
       float hi4[4], lo4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ci = c * 16 + 8 * h + 4 * q + i;
+        const int ci = cc * 16 + 8 * h + 4 * q + i;
         const float ws = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] * mu : 0.f;
         hi4[i] = ws * 0.015625f;
         lo4[i] = (ws - (float)(half_t)ws) * 32.0f;

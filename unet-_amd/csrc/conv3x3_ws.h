@@ -998,6 +998,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         }
       }
     const bool from_zero = a.zinit == nullptr || ks != 0;
+    int4v x9[MW];                                           // EXACT8: the ninth tap's 8-bit operand of the previous chunk, see there
+    if (X8) {
+#pragma unroll
+      for (int m = 0; m < MW; ++m) x9[m] = (int4v){0, 0, 0, 0};     // (finite bytes: a tile's first chunk meets zero weights there)
+    }
     WS_STAMP(3)
     for (int c = c_begin; c < c_end; ++c, ++g) {
       lds_barrier();                                      // chunk g is in stage buffer g & 1
@@ -1118,11 +1123,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           main_step(b, h0, dy, false);
           __builtin_amdgcn_sched_barrier(0);
         }
+        // The ninth tap (2, 2) takes bytes 16-31 of a scaled MFMA whose bytes 0-15 belong to the ninth tap of the PREVIOUS
+        // chunk (x9, kept in registers).  a.pair9 (every layer whose workgroups take an even number of chunks): even chunks
+        // skip the instruction, odd chunks run it for both -- 9 cross MFMAs per two chunks instead of 10; their pair-4 weights
+        // hold both taps (weight_pack_x8_kernel).  Without pair9 every chunk runs it against zero weights in bytes 0-15.
         load_bx(bx0, 4);
+        int4v cur[MW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m) cur[m] = *(const int4v*)(halo + a_off[m + 2][2] + KG * PPP * 16);
         __builtin_amdgcn_sched_barrier(0);
         cross_step(bx1, xa, 0);      // pair 3: taps (0, 2) + (1, 2)
         __builtin_amdgcn_sched_barrier(0);
-        cross_step(bx0, xa, 2);      // pair 4: tap (2, 2) + nothing
+        if (!(a.pair9 && ((c - c_begin) & 1) == 0)) {
+          int8v xq[R];
+#pragma unroll
+          for (int m = 0; m < MW; ++m) xq[m] = __builtin_shufflevector(x9[m], cur[m], 0, 1, 2, 3, 4, 5, 6, 7);
+          cross_step(bx0, xq, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) x9[m] = cur[m];
         __builtin_amdgcn_sched_barrier(0);
         WS_STAMP(1)
         continue;

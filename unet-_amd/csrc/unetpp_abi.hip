@@ -146,6 +146,7 @@ struct unetpp_engine {
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
   int ksplit_max = 16, ksplit_min_chunks = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
   int t_kpart = -1, t_kcnt = -1;  // per slot: partial sums and arrival counters of the split tiles
+  bool pair9 = true;              // EXACT8: ninth taps of consecutive chunks share an MFMA (UNETPP_NO_PAIR9=1: off; read at create)
   bool kcnt_dirty = false;        // a forward returned early: its split launches may have left counters behind
 };
 
@@ -265,7 +266,7 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   int ks = 1;
   if (!UPF && !C0F && !HEAD && a.kpart && a.kcnt && cx.ksplit_max > 1 && tiles * 4 <= cx.num_cus)
     for (int d = 2; d <= cx.ksplit_max && tiles * d <= cx.num_cus && a.nchunks / d >= cx.ksplit_min_chunks; ++d)
-      if (a.nchunks % d == 0) ks = d;
+      if (a.nchunks % d == 0 && !(a.pair9 && (a.nchunks / d) % 2)) ks = d;      // (pair9: whole chunk pairs per workgroup)
   a.ksplit = ks;
   const int total = tiles * ks;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
@@ -630,6 +631,7 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
   const int P = e->P;
 
+  e->pair9 = !getenv("UNETPP_NO_PAIR9");
   if (const char* k = getenv("UNETPP_KSPLIT")) {
     e->ksplit_max = std::max(1, atoi(k));
     if (const char* c = strchr(k, ',')) e->ksplit_min_chunks = std::max(1, atoi(c + 1));
@@ -741,6 +743,10 @@ static bool layer_uses_ws(const unetpp_engine* e, const ConvLayer& L) {
   return e->use_ws && e->P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
 }
 
+// EXACT8: layers whose chunk count is even pair the ninth taps of consecutive chunks (conv3x3_ws.h); the split-K plan then
+// only makes shares with an even number of chunks (launch_ws_k)
+static bool x8_pair9(const unetpp_engine* e, const ConvLayer& L) { return e->x8 && e->pair9 && L.nchunks % 2 == 0; }
+
 static int repack(unetpp_engine* e, hipStream_t s) {
   const int P = e->P;
   for (auto& L : e->convs) {
@@ -751,7 +757,7 @@ static int repack(unetpp_engine* e, hipStream_t s) {
       if ((int)(&L - &e->convs[0]) == e->c0f_conv1) continue;      // conv0_0.conv1 runs in the producers (conv0_pack_kernel below)
       const long long units = (long long)(L.cout / BN) * L.nchunks * 38 * BN;
       hipLaunchKernelGGL(weight_pack_x8_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, w, L.mult, L.cin_real, L.cout, BN,
-                         L.nchunks, (char*)L.wpk, units);
+                         L.nchunks, (char*)L.wpk, units, x8_pair9(e, L) ? 1 : 0);
       continue;
     }
     long long units = (long long)(L.cout / BN) * L.nchunks * P * 9 * (L.KC / 8) * BN;
@@ -925,6 +931,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         a.zinit = L.zt >= 0 ? (const float*)tp(L.zt) : nullptr;
         if (e->t_kpart >= 0) { a.kpart = (float*)tp(e->t_kpart); a.kcnt = (unsigned*)tp(e->t_kcnt); }
         a.ksplit = 1;
+        a.pair9 = x8_pair9(e, L) ? 1 : 0;
         if (L.c0f) {     // the first block reads the caller's tensor itself
           const ConvLayer& L1 = e->convs[e->c0f_conv1];
           a.raw_in = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
