@@ -32,6 +32,18 @@
 // of a tile starts from the MFMA's zero operand; C0F -- the producers compute conv0_0.conv1 themselves (below).
 // Built with -fno-slp-vectorize (unet-_amd/_lib.py): packed fp32 VALU instructions are 5-10x slower beside the
 // consumers' MFMA stream.  Measurement builds (-DUNETPP_WS_DBG): phase ablations and in-kernel phase stamps.
+//
+// EXACT8 (template parameter X8; include/unetpp.h UNETPP_PREC_EXACT8): the split product  x w = hi wh + lo wh + x wl  with
+// the main term in fp16 (one v_mfma_f32_32x32x16_f16 per tap and 16 channels) and BOTH cross terms of TWO taps in one
+// v_mfma_scale_f32_32x32x64_f8f6f4: per lane 32 bytes = [tap A: lo8 x 4, x8 x 4, lo8 x 4, x8 x 4 | tap B: the same] of input
+// channels 8 h .. 8 h + 7 against [wh8 x 4, wl8 x 4, ...] (byte b of a lane meets byte b of the other operand's lane with the
+// same l >> 5: scripts/microbench/scale_mfma_layout.hip).  Encodings and block scales: conv3x3_mfma.h (split_pack4_x8) and
+// aux_kernels.h (weight_pack_x8_kernel).  The pixel records stay 64 bytes with the 8-bit planes where the fp16 lo plane was, so
+// loaders, LDS images and fragment addresses are those of the two-plane format; only the consumers' chunk body, the epilogues'
+// split and the producers that write activations (C0F, UPF) differ.  Logits within 5e-4 of the fp32 reference (bar: 1e-3).
+//
+// Split-K (ConvArgs::ksplit > 1, chosen by launch_ws_k for launches with fewer tiles than a quarter of the CUs): see the
+// consumers' epilogue.
 #pragma once
 #include "conv3x3_mfma.h"
 
@@ -52,7 +64,7 @@ struct WsCfg {
   static constexpr int HALO_PIECES = (NHALO + PPP - 1) / PPP, HALO_BYTES = HALO_PIECES * 1024;
   static constexpr int HALO_ITERS = (HALO_PIECES + NPROD - 1) / NPROD;
   // weight slab of one chunk: P planes of [tap][k-group][BN][8 halves]; X8: the hi plane, then the 8-bit weights of the
-  // five tap pairs [pair][tap of the pair][h][BN][16 bytes] (see the EXACT8 notes above the kernel)
+  // five tap pairs [pair][tap of the pair][h][BN][16 bytes] (EXACT8 notes in the file header)
   static constexpr int SLAB_MAIN = 9 * KC * BN * 2;
   static constexpr int SLAB_BYTES = X8 ? SLAB_MAIN + 5 * 2 * 2 * BN * 16 : P * SLAB_MAIN, SLAB_PIECES = SLAB_BYTES / 1024;
   static constexpr int SLAB_ITERS = (SLAB_PIECES + NPROD - 1) / NPROD;
