@@ -275,3 +275,24 @@ def test_exact8_tapmm_switch_agrees(torch_cuda, syn, oracle, monkeypatch):
     gate("default", l0.cpu().numpy(), m0.cpu().numpy(), ref, ref_mask, oracle)
     gate("UNETPP_TAPMM=none", l1.cpu().numpy(), m1.cpu().numpy(), ref, ref_mask, oracle)
     assert float((l0 - l1).abs().max()) < LOGIT_TOL
+
+
+def test_exact8_microbatch_and_streams_invariance(torch_cuda, syn, monkeypatch):
+    """Micro-batching and concurrent passes on the engine's internal streams never change a bit in exact8 either (one launch
+    plan: the split-K plan of small launches is switched off here; tests/test_gpu_parity.py has its own test)."""
+    from unet_amd.nested_unet import NestedUNet
+    torch = torch_cuda
+    monkeypatch.setenv("UNETPP_KSPLIT", "1")
+    frames = syn.make_frames_u8(5, 64, 96, "smooth", 21)
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    sd = syn.make_state_dict(3, 3, True, 2)
+
+    def model(**kw):
+        m = NestedUNet(3, precision="exact8", max_batch=5, max_hw=(64, 96), **kw).to("cuda:0")
+        m.load_state_dict(sd, strict=True)
+        return m.eval()
+    full, micro, multi = model(), model(micro_batch=2), model(micro_batch=1, streams=3)
+    a = full(x); b = micro(x); c = full(x[3:4]); d = multi(x); d2 = multi(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, d) and torch.equal(a, d2) and torch.equal(a[3:4], c)
+    assert full.status() == 0 and multi.status() == 0

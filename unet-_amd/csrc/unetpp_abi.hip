@@ -144,7 +144,7 @@ struct unetpp_engine {
   bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
   bool use_ws = true;             // exact-mode convs in the wave-specialised kernel (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
-  int ksplit_max = 16, ksplit_min_chunks = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
+  int ksplit_max = 16, ksplit_min_chunks = 4, ksplit_gate = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
   int t_kpart = -1, t_kcnt = -1;  // per slot: partial sums and arrival counters of the split tiles
   bool pair9 = true;              // EXACT8: ninth taps of consecutive chunks share an MFMA (UNETPP_NO_PAIR9=1: off; read at create)
   bool kcnt_dirty = false;        // a forward returned early: its split launches may have left counters behind
@@ -221,7 +221,7 @@ size_t blob_payload_floats(int arch, int C, int cin, int* n_layers = nullptr) {
 }
 
 // ---- conv dispatch ---------------------------------------------------------------------------
-struct LaunchCtx { int device; int num_cus; int ksplit_max = 1, ksplit_min_chunks = 4; };   // per engine: one process may drive engines on several devices
+struct LaunchCtx { int device; int num_cus; int ksplit_max = 1, ksplit_min_chunks = 4, ksplit_gate = 4; };   // per engine: one process may drive engines on several devices
 
 // The conv kernels take more dynamic LDS than the 64 KiB default: raise the function's limit to the whole 160 KiB
 // once per (device, kernel).  The attribute is process-wide state of the HIP runtime and engines may be driven
@@ -264,7 +264,7 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   // The plan depends on (batch, H, W) only; results of different plans differ in summation order (1e-7-class).
   const int tiles = a.N * a.tiles_x * a.tiles_y * a.nct;
   int ks = 1;
-  if (!UPF && !C0F && !HEAD && a.kpart && a.kcnt && cx.ksplit_max > 1 && tiles * 4 <= cx.num_cus)
+  if (!UPF && !C0F && !HEAD && a.kpart && a.kcnt && cx.ksplit_max > 1 && tiles * cx.ksplit_gate <= cx.num_cus)
     for (int d = 2; d <= cx.ksplit_max && tiles * d <= cx.num_cus && a.nchunks / d >= cx.ksplit_min_chunks; ++d)
       if (a.nchunks % d == 0 && !(a.pair9 && (a.nchunks / d) % 2)) ks = d;      // (pair9: whole chunk pairs per workgroup)
   a.ksplit = ks;
@@ -634,7 +634,10 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   e->pair9 = !getenv("UNETPP_NO_PAIR9");
   if (const char* k = getenv("UNETPP_KSPLIT")) {
     e->ksplit_max = std::max(1, atoi(k));
-    if (const char* c = strchr(k, ',')) e->ksplit_min_chunks = std::max(1, atoi(c + 1));
+    if (const char* c = strchr(k, ',')) {
+      e->ksplit_min_chunks = std::max(1, atoi(c + 1));
+      if (const char* g2 = strchr(c + 1, ',')) e->ksplit_gate = std::max(1, atoi(g2 + 1));      // split when tiles * gate <= CUs
+    }
   }
   Builder b{e};
   if (cfg->arch == UNETPP_ARCH_NESTED) build_nested(e, b); else build_simple(e, b);
@@ -978,7 +981,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2, tf(e->x8));
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
-          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus, e->ksplit_max, e->ksplit_min_chunks}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
+          return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus, e->ksplit_max, e->ksplit_min_chunks, e->ksplit_gate}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
                     : launch_conv(LaunchCtx{e->cfg.device, e->num_cus}, P, L, mw, a, head, s);
         });
 #ifdef UNETPP_WS_DBG
