@@ -380,9 +380,10 @@ def run_rank(args) -> int:
         if dom:
             k, (ms, fl, by, cnt) = dom
             tf = fl / (ms * 1e-3) / 1e12
-            # matrix-pipe cycles per product relative to one fp16 MFMA: exact issues 3 MFMAs; exact8 per 16-channel chunk
-            # 9 fp16 MFMAs of 32 cycles + 5 scaled fp8 ones of 64 (two taps each) = 608 / 288
-            mfma_mult = {"exact": 3.0, "exact8": 608.0 / 288.0, "fast": 1.0}[args.precision]
+            # matrix-pipe cycles per product relative to one fp16 MFMA: exact issues 3 MFMAs; exact8 per pair of 16-channel
+            # chunks 18 fp16 MFMAs of 32 cycles + 9 scaled fp8 ones of 64 (two taps each; the ninth taps of the two chunks
+            # share one) = 1152 / 576
+            mfma_mult = {"exact": 3.0, "exact8": 2.0, "fast": 1.0}[args.precision]
             wkey = f"{arch}-c{C}-{H}x{W}-b{B}-{args.precision}"
             traffic, tsrc = measured_traffic(k, wkey)
             roofline = {"bound": "mfma", "kernel": k, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
