@@ -215,8 +215,10 @@ const char* unetpp_profile_name(const unetpp_engine* e, int i);
 int unetpp_profile_work(const unetpp_engine* e, int i, double* flops, double* bytes);
 
 /* ---- debug (layer-by-layer parity tests) -------------------------------------------------------
- * Copies the named activation of the LAST micro-batch processed ("x0_0", "x1_0", ..., "x0_4") to
- * host memory as float32 [b,C,h,w]; returns the number of floats written or a negative error. */
+ * Copies the named activation of the LAST micro-batch processed ("x0_0", "x1_0", ..., "x0_4"; also a block's first conv
+ * "x1_0a" and a pooled tensor "x1_0p" [b,C,h/2,w/2]) to host memory as float32 [b,C,h,w]; returns the number of floats
+ * written or a negative error.  "name#hi", "name#lo", "name#x8" give one stored plane instead of the reconstructed value
+ * (fp16 hi; fp16 lo, or EXACT8's decoded e5m2(2^8 lo); EXACT8's decoded e5m2(2^-3 v)). */
 long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out, size_t max_floats);
 
 /* x0_4 is normally never written to HBM (the 1x1 head + argmax run in the epilogue of conv0_4.conv2).

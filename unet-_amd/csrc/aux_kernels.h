@@ -519,9 +519,11 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const uint8_t* __restri
   }
 }
 
-// debug: channel-blocked fp16 -> float32 NCHW
+// debug: channel-blocked planes -> float32 NCHW.  plane 0: the value a reader reconstructs (hi [+ lo | + 2^-8 lo8]);
+// 1: the hi plane alone; 2: the second plane as stored (fp16 lo, or the decoded e5m2 lo8 = e5m2(2^8 lo)); 3: EXACT8's decoded
+// x8 = e5m2(2^-3 v) -- the layer-by-layer arithmetic test (tests/test_gpu_exact8.py) needs the planes themselves.
 template <int P>
-__global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, int H, int W, float* __restrict__ out) {
+__global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, int H, int W, float* __restrict__ out, int plane) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * C * H * W;
   if (i >= total) return;
@@ -531,11 +533,15 @@ __global__ void unpack_nchw_kernel(const half_t* __restrict__ x, int N, int C, i
   const int CB = C < 16 ? C : 16;                 // channel-blocked source: [N][C/CB][H][W][P][CB]
   const half_t* p = x + ((((size_t)(n * (C / CB) + c / CB) * H + y) * W + xx) * (P == 3 ? 2 : P)) * CB + c % CB;
   float v = (float)p[0];
-  if (P == 2) v += (float)p[CB];
-  if (P == 3) {          // EXACT8 record (CB = 16): hi + 2^-8 lo8, lo8 at byte 32 + 16 (c / 8) + 8 ((c / 4) & 1) + c % 4
+  if (P == 2) {
+    const float lo = (float)p[CB];
+    v = plane == 0 ? v + lo : plane == 2 ? lo : v;
+  }
+  if (P == 3) {          // EXACT8 record (CB = 16): lo8 at byte 32 + 16 (c / 8) + 8 ((c / 4) & 1) + c % 4, x8 four bytes behind it
     const int cc = c % 16;
-    const unsigned char b8 = ((const unsigned char*)(p - cc))[32 + 16 * (cc >> 3) + 8 * ((cc >> 2) & 1) + (cc & 3)];
-    v += __builtin_amdgcn_cvt_scalef32_f32_bf8((int)b8, X8_LO_MUL, 0);
+    const unsigned char* q = (const unsigned char*)(p - cc) + 32 + 16 * (cc >> 3) + 8 * ((cc >> 2) & 1) + (cc & 3);
+    const float l8 = __builtin_amdgcn_cvt_scalef32_f32_bf8((int)q[0], 1.0f, 0), x8 = __builtin_amdgcn_cvt_scalef32_f32_bf8((int)q[4], 1.0f, 0);
+    v = plane == 0 ? v + l8 * X8_LO_MUL : plane == 2 ? l8 : plane == 3 ? x8 : v;
   }
   out[i] = v;
 }

@@ -1253,9 +1253,19 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   if (e->last_b == 0) return fail(e, UNETPP_E_STATE, "debug_read before forward");
   const Tensor* t = nullptr;
   int tid = -1;
+  // "name#hi", "name#lo", "name#x8": one stored plane instead of the reconstructed value (see unpack_nchw_kernel)
+  std::string base(name);
+  int plane = 0;
+  if (size_t hash = base.find('#'); hash != std::string::npos) {
+    const std::string sel = base.substr(hash + 1);
+    base.resize(hash);
+    plane = sel == "hi" ? 1 : sel == "lo" ? 2 : sel == "x8" ? 3 : -1;
+    if (plane < 0 || (plane == 3 && !e->x8) || (plane == 2 && e->P != 2))
+      return fail(e, UNETPP_E_INVALID, "plane '%s' does not exist in this engine's activation format", sel.c_str());
+  }
   for (size_t i = 0; i < e->tensors.size(); ++i)
-    if (e->tensors[i].name == name) { t = &e->tensors[i]; tid = (int)i; }
-  if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", name);
+    if (e->tensors[i].name == base) { t = &e->tensors[i]; tid = (int)i; }
+  if (!t) return fail(e, UNETPP_E_INVALID, "unknown tensor '%s'", base.c_str());
   if (t->virt) return fail(e, UNETPP_E_STATE, "'%s' is never materialised on this engine (fused into its consumer)", name);
   if (t->C == 0) return fail(e, UNETPP_E_STATE, "'%s' is not an activation tensor (raw fp32 / bookkeeping buffer)", name);
   if (e->cfg.arch == UNETPP_ARCH_NESTED && tid == e->t_head_in && !e->keep_all)
@@ -1269,9 +1279,9 @@ long long unetpp_debug_read(unetpp_engine* e, const char* name, float* host_out,
   HIP_TRY(e, hipDeviceSynchronize());
   HIP_TRY(e, hipMalloc((void**)&tmp, total * sizeof(float)));
   const half_t* src = (const half_t*)(e->arena + e->last_slot_off + t->off);
-  if (e->x8) hipLaunchKernelGGL(unpack_nchw_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
-  else if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
-  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp);
+  if (e->x8) hipLaunchKernelGGL(unpack_nchw_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp, plane);
+  else if (e->P == 2) hipLaunchKernelGGL(unpack_nchw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp, plane);
+  else hipLaunchKernelGGL(unpack_nchw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, src, nb, t->C, H, W, tmp, plane);
   hipError_t st = hipMemcpy(host_out, tmp, total * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(tmp);
   if (st != hipSuccess) return fail(e, UNETPP_E_HIP, "debug copy: %s", hipGetErrorString(st));
