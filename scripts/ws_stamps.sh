@@ -8,6 +8,6 @@ H=$(python -c 'from unet_amd import _lib; print(_lib.source_hash())')
 FLAGS=$(python -c 'from unet_amd import _lib; print(" ".join(_lib.CXXFLAGS))')
 (cd unet-_amd/csrc && /opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DUNETPP_WS_DBG=1 -DUNETPP_SRC_HASH=\"$H\" -o ../libunetpp_hip.so unetpp_abi.hip)
 for l in "$@"; do
-  UNETPP_ALLOW_DBG_LIB=1 UNETPP_WS_STAMPS=$l timeout -k 10 120 python scripts/layer_profile.py ${PREC:-exact} ${BATCH:-16} 2>&1 | grep -A2 "stamps\|^$l" | grep -v "^--" || true
+  UNETPP_ALLOW_DBG_LIB=1 UNETPP_WS_STAMPS=$l timeout -k 10 120 python scripts/layer_profile.py ${PREC:-exact} ${BATCH:-16} 2>&1 | grep -A12 "stamps\|^$l" | grep -v "^--" || true
 done
 UNETPP_FORCE_BUILD=1 python __graft_entry__.py > /dev/null

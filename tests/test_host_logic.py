@@ -147,3 +147,20 @@ def test_precision_codes_match_the_header():
     with pytest.raises(ValueError):
         NestedUNet(3, precision="exact16")
     assert NestedUNet(3, precision="exact8").precision == "exact8"      # construction needs no device
+
+
+def test_reciprocal_tile_decode_is_off_by_at_most_one():
+    """conv3x3_ws.h decodes a workgroup's first tile number with one float reciprocal per radix digit and a single
+    correction step (its `divmod`), valid below 2^22 tiles: whatever way v_rcp_f32 rounds (1 ulp), the truncated float
+    quotient is within one of the true quotient, so the corrected (q, r) are exact."""
+    rng = np.random.default_rng(7)
+    u = np.concatenate([rng.integers(0, 1 << 22, 200_000), np.arange(0, 4096), (1 << 22) - 1 - np.arange(0, 4096)]).astype(np.int64)
+    d = np.concatenate([rng.integers(1, 1 << 14, 200_000), rng.integers(1, 64, 8192)]).astype(np.int64)
+    rcp = (np.float32(1.0) / d.astype(np.float32)).astype(np.float32)
+    for bump in (-1, 0, 1):                                   # the hardware reciprocal: correctly rounded +- 1 ulp
+        r32 = (rcp.view(np.int32) + bump).view(np.float32)
+        q = (u.astype(np.float32) * r32).astype(np.float32).astype(np.int64)          # v_cvt_i32_f32 truncates
+        r = u - q * d
+        up, dn = (r >= d).astype(np.int64), (r < 0).astype(np.int64)
+        q2, r2 = q + up - dn, r + (dn - up) * d
+        assert np.array_equal(q2, u // d) and np.array_equal(r2, u % d)

@@ -59,6 +59,7 @@ struct ConvArgs {
   int ksplit;            // >= 1, divides nchunks
   float* kpart;          // [ksplit][tiles][4 consumer waves][MW * NW * 16 * 64] fp32
   unsigned* kcnt;        // [tiles][4], zero between launches
+  int gdec[5];           // wave-specialised kernel: the grid size in the tile-number radix (ks, ct, tx, ty, n), by the host (launch_ws_k)
   int pair9;             // EXACT8: the ninth tap of an even chunk shares a scaled MFMA with the next chunk's (conv3x3_ws.h)
   // fused 1x1 head + argmax (HEAD variant, Cout == 32 == BN): self.final (unetpp.py:85,119) and the
   // frame-loop tail softmax->argmax->uint8, (pred==1), (pred==2) (infer_two_stage_burr.py:299-304)

@@ -247,6 +247,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   constexpr int KC = C::KC, KG = C::KG, BN = C::BN, PPP = C::PPP;
   static_assert(!(POOL && HEAD) && !(UPF && (POOL || HEAD)), "one fused extra per kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef UNETPP_WS_DBG
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  // The argument block is nine cache lines and the compiler fetches a field when it first needs it: every first touch of a line
+  // is a miss of the (just invalidated) scalar cache, one after the other on the producers' path to their first DMA -- a
+  // microsecond or more per launch.  Touch all lines at once instead; the fields hit afterwards.
+  {
+    const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int touched = 0;
+#pragma unroll
+    for (int o = 0; o < (int)(sizeof(ConvArgs) / 4); o += 16) touched |= ka[o];
+    asm volatile("" :: "s"(touched));
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -274,6 +287,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     }
   }
 
+#ifdef UNETPP_WS_DBG
+  const unsigned long long rt_staged = __builtin_amdgcn_s_memrealtime();
+#endif
   // tile order as in conv3x3_bias_relu_kernel: an XCD (workgroups b, b+8, ...) walks a contiguous run of tiles
   const int G = (int)gridDim.x;
   const int slot = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
@@ -281,15 +297,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   // same tile again): only the first call divides, later ones add G's own decomposition with carries (wave-uniform
   // scalar work; the six divisions per tile used to cost several hundred cycles in each role).
   int dec_ks = 0, dec_ct = 0, dec_tx = 0, dec_ty = 0, dec_n = 0, dec_t = -1;      // the tile decoded last (per-wave cursor)
-  int g_ks, g_ct, g_tx, g_ty, g_n;
-  {
-    int t = G;
-    g_ks = t % KS; t /= KS;
-    g_ct = t % a.nct; t /= a.nct;
-    g_tx = t % a.tiles_x; t /= a.tiles_x;
-    g_ty = t % a.tiles_y;
-    g_n = t / a.tiles_y;
-  }
+  // (G's own decomposition comes from the host: five scalar divisions are ~150 dependent instructions, and at one tile
+  // per workgroup -- a small batch -- the whole launch waits for the producers' path to their first DMA)
+  const int g_ks = a.gdec[0], g_ct = a.gdec[1], g_tx = a.gdec[2], g_ty = a.gdec[3], g_n = a.gdec[4];
+  // u = q d + r for wave-uniform 0 <= u < 2^22, d >= 1: one reciprocal and a branch-free correction step instead of the
+  // generic 32-bit division (below 2^22 the float quotient is off by at most one)
+  const bool small_radix = total_tiles < (1 << 22);
+  auto divmod = [&](const int u, const int d, int& q, int& r) {      // (q may alias the caller's u)
+    int qq, rr;
+    if (small_radix) {
+      qq = (int)((float)u * __builtin_amdgcn_rcpf((float)d));
+      rr = u - qq * d;
+      const int up = rr >= d ? 1 : 0, dn = rr < 0 ? 1 : 0;
+      qq += up - dn; rr += (dn - up) * d;
+    } else {
+      qq = u / d; rr = u - qq * d;
+    }
+    q = qq; r = rr;
+  };
   auto decode = [&](int t, int& n, int& y0, int& x0) {
     if (t != dec_t) {
       if (dec_t >= 0 && t == dec_t + G) {
@@ -308,11 +333,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         dec_n += g_n + carry;
       } else {
         int u = t;
-        dec_ks = u % KS; u /= KS;
-        dec_ct = u % a.nct; u /= a.nct;
-        dec_tx = u % a.tiles_x; u /= a.tiles_x;
-        dec_ty = u % a.tiles_y;
-        dec_n = u / a.tiles_y;
+        divmod(u, KS, u, dec_ks);
+        divmod(u, a.nct, u, dec_ct);
+        divmod(u, a.tiles_x, u, dec_tx);
+        divmod(u, a.tiles_y, dec_n, dec_ty);
       }
       dec_t = t;
     }
@@ -414,11 +438,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   if (C0F) __syncthreads();                              // C0F: slabs, zero words and the first patch visible to all producer waves
 
 #ifdef UNETPP_WS_DBG
-#define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; }
+#define WS_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_sum[i] += now_ - st_t; st_t = now_; \
+                      if (ev_ptr && ev_ptr < ev_end) *ev_ptr++ = ((unsigned long long)(i) << 56) | __builtin_amdgcn_s_memrealtime(); }
+// event log of one wave per role (dbg bit 131072, single-layer stamps only): (phase << 56 | 100 MHz wall clock) after every phase, 60 events
+#define WS_EVLOG(role) unsigned long long* ev_ptr = (a.stamps && (a.dbg & 131072) && lane == 0 && blockIdx.x < 1024) ? a.stamps + (size_t)1024 * 32 + ((size_t)blockIdx.x * 2 + (role)) * 64 : nullptr; \
+                       unsigned long long* const ev_end = ev_ptr + 60; if (ev_ptr) *ev_ptr++ = (63ull << 56) | rt_entry;
 #define WS_STAMP_IN(i) if (a.dbg & 32768) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); WS_STAMP(i) __builtin_amdgcn_sched_barrier(0); }
+#define WS_EVT(i) { if (ev_ptr && ev_ptr < ev_end) *ev_ptr++ = ((unsigned long long)(i) << 56) | __builtin_amdgcn_s_memrealtime(); }
 #else
 #define WS_STAMP(i) {}
 #define WS_STAMP_IN(i) {}
+#define WS_EVT(i) {}
 #endif
   if (C0F && wave >= C::NCONS) {
     // =============================================================== producers, fused first block
@@ -427,6 +457,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     // stamps: [0] patch prefetch issue, [1] conv1 groups, [2] patch store, [3] barrier
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = __builtin_readcyclecounter();
+    WS_EVLOG(1)
+    if (pw != 0) ev_ptr = nullptr;
 #endif
 #ifndef UNETPP_C0_PRIO
 #define UNETPP_C0_PRIO 1
@@ -569,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     if (a.stamps && pw == 0 && lane == 0)
 #pragma unroll
       for (int i = 0; i < 11; ++i) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + i] = st_sum[i];
+    if (a.stamps && pw == 0 && lane == 0) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 #endif
     return;
   }
@@ -577,6 +610,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     // =============================================================== producers
     const int pw = wave - C::NCONS;
 #ifdef UNETPP_WS_DBG
+    const unsigned long long rt_prod = __builtin_amdgcn_s_memrealtime();
     { const int pr = (a.dbg >> 10) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3); }
 #endif
     constexpr unsigned OOB = 0x80000000u;                // beyond num_records: the buffer load returns zeros
@@ -717,6 +751,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     // [8] corner reads issued and landed, [9] arithmetic, [10] stores issued and retired (instead of [4])
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_t = 0;
+    WS_EVLOG(1)
+    if (pw != 0) ev_ptr = nullptr;
+    if (ev_ptr) { *ev_ptr++ = (48ull << 56) | rt_staged; *ev_ptr++ = (49ull << 56) | rt_prod; }
+    WS_EVT(50)
 #endif
     // all interpolation items of this lane for up-chunk c: staging buffer (c & 1) -> halo image.  Straight-line code
     // for all rounds (the LDS reads of every round are issued before the first value is needed; a lane without an
@@ -828,17 +866,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     };
     int g = 0;                                           // global chunk counter: chunk g -> stage buffer g & 1
     const bool slabs_stay = a.nchunks == 2 && a.nct == 1 && KS == 1;
+    const int chunks_per_share = KS == 1 ? a.nchunks : a.nchunks / KS;
 #ifdef UNETPP_WS_DBG
     st_t = __builtin_readcyclecounter();
 #endif
+    WS_EVT(51)
     for (int tile = slot; tile < total_tiles; tile += G) {
       int n, y0, x0;
       decode(tile, n, y0, x0);
-      setup_tile(n, y0, x0);
-      WS_STAMP(7)
+      WS_EVT(52)
       const char* wsrc = (const char*)a.wpk + (size_t)dec_ct * a.nchunks * C::SLAB_BYTES;
       const int tile_ct = dec_ct;
-      const int c_begin = dec_ks * (a.nchunks / KS), c_end = c_begin + a.nchunks / KS;       // this workgroup's share of K
+      const int c_begin = dec_ks * chunks_per_share, c_end = c_begin + chunks_per_share;       // this workgroup's share of K
+      setup_tile(n, y0, x0);
+      WS_STAMP(7)
       for (int c = c_begin; c < c_end; ++c, ++g) {
         const int buf = (g & 1) * C::BUF_BYTES;
 #ifdef UNETPP_WS_DBG
@@ -904,6 +945,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
     if (a.stamps && pw == 0 && lane == 0)
 #pragma unroll
       for (int i = 0; i < 11; ++i) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + i] = st_sum[i];
+    if (a.stamps && pw == 0 && lane == 0) a.stamps[((size_t)blockIdx.x * 2 + 1) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 #endif
     return;
   }
@@ -985,6 +1027,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [0] barrier, [1] chunk, [2] epilogue, [3] accumulator init
   unsigned long long st_t = __builtin_readcyclecounter();
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();     // 100 MHz, one clock for the whole chip
+  WS_EVLOG(0)
+  if (cw != 0) ev_ptr = nullptr;
+  if (ev_ptr) *ev_ptr++ = (62ull << 56) | rt_begin;
 #endif
   for (int tile = slot; tile < total_tiles; tile += G) {
     int n, y0, x0;
@@ -1282,6 +1328,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   if (a.stamps && cw == 0 && lane == 0)
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.stamps[((size_t)blockIdx.x * 2) * 16 + i] = st_sum[i];
+  if (a.stamps && cw == 0 && lane == 0) {
+    a.stamps[((size_t)blockIdx.x * 2) * 16 + 4] = rt_begin;
+    a.stamps[((size_t)blockIdx.x * 2) * 16 + 6] = rt_entry;
+    a.stamps[((size_t)blockIdx.x * 2) * 16 + 5] = __builtin_amdgcn_s_memrealtime();
+  }
 #endif
 }
 #undef WS_STAMP

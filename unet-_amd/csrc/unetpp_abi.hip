@@ -270,6 +270,14 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   a.ksplit = ks;
   const int total = tiles * ks;
   dim3 grid((unsigned)std::min(total, cx.num_cus));
+  {      // the grid size in the kernel's tile-number radix (its workgroups step through the tiles by G)
+    int t = (int)grid.x;
+    a.gdec[0] = t % ks; t /= ks;
+    a.gdec[1] = t % a.nct; t /= a.nct;
+    a.gdec[2] = t % a.tiles_x; t /= a.tiles_x;
+    a.gdec[3] = t % a.tiles_y;
+    a.gdec[4] = t / a.tiles_y;
+  }
   auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW, X8>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
@@ -742,6 +750,9 @@ void unetpp_destroy(unetpp_engine* e) {
 size_t unetpp_workspace_bytes(const unetpp_engine* e) { return e ? e->arena_bytes : 0; }
 
 // which conv layers run in the wave-specialised kernel (a property of the engine and the layer, not of a call)
+#ifdef UNETPP_WS_DBG
+static unsigned long long* unetpp_dbg_stamp_buf = nullptr;     // measurement build: in-kernel stamps (scripts/ws_stamps.sh)
+#endif
 static bool layer_uses_ws(const unetpp_engine* e, const ConvLayer& L) {
   return e->use_ws && e->P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
 }
@@ -908,6 +919,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
     uint8_t* tpe = dev_tape ? dev_tape + (size_t)b0 * hw : nullptr;
     float* pr = dev_probs ? dev_probs + (size_t)b0 * C * hw : nullptr;
     bool head_done = false;
+#ifdef UNETPP_WS_DBG
+    std::vector<std::string> dbg_timeline;                   // UNETPP_WS_STAMPS=all: the wave-specialised launches of this pass, in order
+#endif
 
     for (const Op& op : e->ops) {
       if (op.kind == OP_CONVERT) {
@@ -943,13 +957,15 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         }
 #ifdef UNETPP_WS_DBG
         { const char* d = getenv("UNETPP_WS_DBG"); a.dbg = d ? atoi(d) : 0; }
-        static unsigned long long* stamp_buf = nullptr;
+        unsigned long long*& stamp_buf = unetpp_dbg_stamp_buf;
         const char* stamp_layer = getenv("UNETPP_WS_STAMPS");      // layer name: print that launch's in-kernel phase times
+        const bool stamp_all = stamp_layer && !strcmp(stamp_layer, "all");      // "all": one wall-clock timeline of the forward
         const bool stamp_this = stamp_layer && L.name == stamp_layer;
-        if (stamp_this) {
-          if (!stamp_buf) (void)hipMalloc((void**)&stamp_buf, 1024 * 32 * 8);
-          (void)hipMemsetAsync(stamp_buf, 0, 1024 * 32 * 8, s);
-          a.stamps = stamp_buf;
+        if (stamp_this || stamp_all) {
+          if (!stamp_buf) { (void)hipMalloc((void**)&stamp_buf, (size_t)32 * 1024 * 32 * 8); (void)hipMemset(stamp_buf, 0, (size_t)32 * 1024 * 32 * 8); }
+          if (stamp_this) (void)hipMemsetAsync(stamp_buf, 0, 1024 * 32 * 8 * 5, s);
+          a.stamps = stamp_buf + (stamp_all ? (size_t)(1 + dbg_timeline.size()) * 1024 * 32 : 0);
+          if (stamp_all) dbg_timeline.push_back(L.name);
         }
 #endif
         const int mw = small_grid_rows(L, e->num_cus, nb, H, W, head);
@@ -987,7 +1003,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
 #ifdef UNETPP_WS_DBG
         if (stamp_this && ws) {
           static int printed = 0;
-          std::vector<unsigned long long> hs(1024 * 32);
+          std::vector<unsigned long long> hs(1024 * 32 * 5);
           (void)hipStreamSynchronize(s);
           (void)hipMemcpy(hs.data(), stamp_buf, hs.size() * 8, hipMemcpyDeviceToHost);
           if (printed++ == 3) {      // a warm launch
@@ -997,6 +1013,29 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
             fprintf(stderr, "[stamps %s] %d workgroups, mean cycles per workgroup:\n  consumer: barrier %.0f  chunks %.0f  epilogue %.0f  init %.0f\n"
                             "  producer: skip issue %.0f wait %.0f barrier %.0f | up issue %.0f interp %.0f (reads %.0f arithmetic %.0f split+stores %.0f) wait %.0f barrier %.0f | setup %.0f\n", L.name.c_str(), nwg,
                     sum[0] / nwg, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[16] / nwg, sum[17] / nwg, sum[18] / nwg, sum[19] / nwg, sum[20] / nwg, sum[24] / nwg, sum[25] / nwg, sum[26] / nwg, sum[21] / nwg, sum[22] / nwg, sum[23] / nwg);
+            // wall-clock (100 MHz) begin / end of consumer wave 0 of every workgroup, relative to the earliest begin
+            std::vector<double> bg, en;
+            unsigned long long t0 = ~0ull;
+            std::vector<double> cb, pe;
+            for (int b = 0; b < 1024; ++b) if (hs[b * 32 + 6]) t0 = std::min(t0, hs[b * 32 + 6]);
+            for (int b = 0; b < 1024; ++b) if (hs[b * 32 + 6]) {
+              bg.push_back((hs[b * 32 + 6] - t0) * 0.01); en.push_back((hs[b * 32 + 5] - t0) * 0.01);
+              cb.push_back((hs[b * 32 + 4] - t0) * 0.01); pe.push_back((hs[b * 32 + 16 + 12] - t0) * 0.01);
+            }
+            std::sort(bg.begin(), bg.end()); std::sort(en.begin(), en.end()); std::sort(cb.begin(), cb.end()); std::sort(pe.begin(), pe.end());
+            if (!bg.empty()) fprintf(stderr, "  consumer loop begins p50 %.2f max %.2f | producer wave 0 ends p50 %.2f max %.2f\n", cb[cb.size() / 2], cb.back(), pe[pe.size() / 2], pe.back());
+            if (a.dbg & 131072)
+              for (int b : {0, 1, 100, 200}) {      // event logs of consumer wave 0 and producer wave 0 (phase:us after the earliest kernel entry)
+                for (int role = 0; role < 2; ++role) {
+                  fprintf(stderr, "  wg %3d %s:", b, role ? "producer" : "consumer");
+                  const unsigned long long* ev = hs.data() + 1024 * 32 + ((size_t)b * 2 + role) * 64;
+                  for (int i = 0; i < 60 && ev[i]; ++i) fprintf(stderr, " %d:%.2f", (int)(ev[i] >> 56), (double)((ev[i] & 0xffffffffffffffull) - t0) * 0.01);
+                  fprintf(stderr, "\n");
+                }
+              }
+            if (!bg.empty())
+              fprintf(stderr, "  wall clock (us after the first workgroup's kernel entry): entry p50 %.2f p90 %.2f max %.2f | end min %.2f p50 %.2f p90 %.2f max %.2f\n",
+                      bg[bg.size() / 2], bg[bg.size() * 9 / 10], bg.back(), en.front(), en[en.size() / 2], en[en.size() * 9 / 10], en.back());
           }
         }
 #endif
@@ -1088,6 +1127,30 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
       }
     }
     if (Lx.rc) return Lx.rc;
+#ifdef UNETPP_WS_DBG
+    if (!dbg_timeline.empty()) {
+      // wall-clock (100 MHz, chip-wide) entry of the first workgroup and end of the last consumer-0 / producer-0 wave of every
+      // wave-specialised launch, relative to the first launch's entry: what lies between the launches
+      static int pass = 0;
+      if (++pass == 6) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> hs((size_t)(1 + dbg_timeline.size()) * 1024 * 32);
+        (void)hipMemcpy(hs.data(), unetpp_dbg_stamp_buf, hs.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long T0 = ~0ull;
+        double prev_end = 0;
+        for (size_t li = 0; li < dbg_timeline.size(); ++li) {
+          const unsigned long long* r = hs.data() + (1 + li) * 1024 * 32;
+          unsigned long long first = ~0ull, last = 0; int nwg = 0;
+          for (int b = 0; b < 1024; ++b) if (r[b * 32 + 6]) { ++nwg; first = std::min(first, r[b * 32 + 6]); last = std::max(last, std::max(r[b * 32 + 5], r[b * 32 + 16 + 12])); }
+          if (!nwg) continue;
+          if (T0 == ~0ull) T0 = first;
+          const double b0 = (first - T0) * 0.01, e0 = (last - T0) * 0.01;
+          fprintf(stderr, "[timeline] %-16s %4d wg  entry %8.2f  end %8.2f  inside %6.2f  since previous end %6.2f\n", dbg_timeline[li].c_str(), nwg, b0, e0, e0 - b0, b0 - prev_end);
+          prev_end = e0;
+        }
+      }
+    }
+#endif
   }
   HIP_TRY(e, join.run());
   e->kcnt_dirty = Lx.rc != UNETPP_OK;
