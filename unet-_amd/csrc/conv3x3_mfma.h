@@ -178,6 +178,19 @@ typedef __attribute__((address_space(3))) char lds_char_t;
 // flat access that may alias LDS and then degrades every later `s_waitcnt lgkmcnt(N)` of the MFMA loop
 // to lgkmcnt(0) (no ds_read prefetch overlap).  The asm is invisible to the compiler's counters, so
 // the consumer side waits explicitly: `s_waitcnt vmcnt(0)` before the barrier that publishes the buffer.
+// A kernel's argument block spans several cache lines and the compiler fetches a field when it first needs it: every first
+// touch of a line is a miss of the scalar cache (invalidated at the launch boundary), one after the other on the way to the
+// first DMA -- about a microsecond per launch with ConvArgs' nine lines (profiles/r03_b1_timeline.txt).  Touch all lines in
+// one burst at kernel entry; the fields hit afterwards.
+template <class Args>
+__device__ __forceinline__ void touch_kernarg_lines() {
+  const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
+  int touched = 0;
+#pragma unroll
+  for (int o = 0; o < (int)(sizeof(Args) / 4); o += 16) touched |= ka[o];
+  asm volatile("" :: "s"(touched));
+}
+
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -330,6 +343,7 @@ template <int P, bool HEAD> constexpr bool conv_single_stage() { return HEAD && 
 template <int P, int KC, int NW, int MW, int WAVES, bool POOL, bool HEAD = false, bool UPF = false, bool ZINIT = false>
 __global__ __launch_bounds__(WAVES * 64, (conv_single_stage<P, HEAD>() ? 2 : 1))
 void conv3x3_bias_relu_kernel(ConvArgs a) {
+  touch_kernarg_lines<ConvArgs>();
   using C = ConvCfg<P, KC, NW, MW, WAVES, conv_single_stage<P, HEAD>(), UPF>;
   static_assert(!UPF || (!POOL && !HEAD && KC == 16 && MW == 2 && !conv_single_stage<P, HEAD>()), "fused upsample: plain 16-row tiles only");
   constexpr int NT = C::NT, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;

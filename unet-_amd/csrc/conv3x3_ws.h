@@ -250,16 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
 #ifdef UNETPP_WS_DBG
   const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-  // The argument block is nine cache lines and the compiler fetches a field when it first needs it: every first touch of a line
-  // is a miss of the (just invalidated) scalar cache, one after the other on the producers' path to their first DMA -- a
-  // microsecond or more per launch.  Touch all lines at once instead; the fields hit afterwards.
-  {
-    const int* ka = (const int*)__builtin_amdgcn_kernarg_segment_ptr();
-    int touched = 0;
-#pragma unroll
-    for (int o = 0; o < (int)(sizeof(ConvArgs) / 4); o += 16) touched |= ka[o];
-    asm volatile("" :: "s"(touched));
-  }
+  touch_kernarg_lines<ConvArgs>();                      // (conv3x3_mfma.h: nine serialised scalar-cache misses otherwise)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

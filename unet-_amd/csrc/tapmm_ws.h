@@ -54,6 +54,7 @@ template <bool X8>
 __global__ __launch_bounds__(512, 2) void tapmm_ws_kernel(TapmmArgs a) {
   using C = TapmmCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  touch_kernarg_lines<TapmmArgs>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(unsigned long)(lds_char_t*)smem;
