@@ -4,7 +4,7 @@
 #   bits: 1 no interpolation, 2 no halo / low-res DMA, 4 no MFMAs, 8 no slab DMA, 16 no consumer work at all,
 #         32 corner reads of the interpolation in the old (2-way conflicting) order, 64 interpolation without split + stores,
 #         128 no DMA wait, 256 no epilogue, 512 interpolation without corner reads; bits 10-11 producer s_setprio,
-#         12-13 consumer s_setprio; 16384 halo DMA with a pixel's units on neighbouring lanes; 32768 stamps inside the
+#         12-13 consumer s_setprio; 16384 halo DMA with a pixel's units on neighbouring lanes; 262144 epilogue without its global stores; 32768 stamps inside the
 #         interpolation (scripts/ws_stamps.sh).  Results are garbage -- and so are the operands of later layers: the
 #         chip's clock depends on the data, compare a layer only with itself.
 # usage (on the GPU box, from the repo root): [PREC=exact8] [BATCH=1] [LAYERS='conv1_3\|conv0_4'] scripts/ws_ablate.sh 0 1 4 256 ...

@@ -301,7 +301,7 @@ __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* 
 // of the tile's first record, registers 8..15 the same eight of the second -- the stores of pack_store_octets without
 // its exchange between the half-waves.
 template <int P, bool X8 = false>
-__device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
+__device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h, bool dbg_nostore = false, bool dbg_coalesced = false) {
 #pragma unroll
   for (int pi = 0; pi < 2; ++pi) {
     unsigned wh[4], wl[4];
@@ -319,6 +319,22 @@ __device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* d
         wh[i] = __builtin_bit_cast(unsigned, ph);
       }
     }
+#ifdef UNETPP_WS_DBG
+    if (dbg_nostore) {      // timing experiment: the whole epilogue except its global stores
+      asm volatile("" :: "v"(wh[0]), "v"(wh[1]), "v"(wh[2]), "v"(wh[3]));
+      if (P == 2) asm volatile("" :: "v"(wl[0]), "v"(wl[1]), "v"(wl[2]), "v"(wl[3]));
+      continue;
+    }
+    if (dbg_coalesced) {    // timing experiment: the same bytes to the same 2 KB row, one contiguous KB per instruction (WRONG data placement)
+      const int lane_ = (int)(threadIdx.x & 63), p_ = lane_ & 31;
+      half_t* row = dst - p_ * (P * 16) + pi * blk_stride;
+      if (ok) {
+        *(u32x4*)(row + lane_ * 8) = (u32x4){wh[0], wh[1], wh[2], wh[3]};
+        if (P == 2) *(u32x4*)(row + 512 + lane_ * 8) = (u32x4){wl[0], wl[1], wl[2], wl[3]};
+      }
+      continue;
+    }
+#endif
     if (ok) {
       *(u32x4*)(dst + pi * blk_stride + 8 * h) = (u32x4){wh[0], wh[1], wh[2], wh[3]};
       if (P == 2) *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = (u32x4){wl[0], wl[1], wl[2], wl[3]};

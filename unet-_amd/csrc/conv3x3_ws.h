@@ -137,7 +137,11 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = gy < H && gx < W;
       const size_t blk = (size_t)H * W * P * 16;
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)gy * W + gx) * P * 16;
+#ifdef UNETPP_WS_DBG
+      pack_store_rows8<P, X8>(v[m], dst, blk, ok, h, (a.dbg & 262144) != 0, (a.dbg & 524288) != 0);
+#else
       pack_store_rows8<P, X8>(v[m], dst, blk, ok, h);
+#endif
     }
   } else {
     // logits[c] = b[c] + sum_co x0_4[co] * Wf[c][co] in fp32: a lane holds 16 of a pixel's 32 channels, lane ^ 32 the
@@ -223,7 +227,11 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
       const bool ok = ((lane & 1) == 0) && py < Hp && px < Wp;
       const size_t blk = (size_t)Hp * Wp * P * 16;
       half_t* dst = a.pool_out + ((size_t)n * nbo + (cbase >> 4)) * blk + ((size_t)py * Wp + px) * P * 16;
+#ifdef UNETPP_WS_DBG
+      pack_store_rows8<P, X8>(pv, dst, blk, ok, h, (a.dbg & 262144) != 0);
+#else
       pack_store_rows8<P, X8>(pv, dst, blk, ok, h);
+#endif
     }
   }
 }

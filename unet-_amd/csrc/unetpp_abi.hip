@@ -957,6 +957,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         }
 #ifdef UNETPP_WS_DBG
         { const char* d = getenv("UNETPP_WS_DBG"); a.dbg = d ? atoi(d) : 0; }
+        // UNETPP_WS_DBG_ONLY=layer: the ablation applies to that launch alone -- its inputs stay genuine (a layer fed with the
+        // zeros an ablated predecessor leaves behind runs at a different clock)
+        { const char* only = getenv("UNETPP_WS_DBG_ONLY"); if (only && L.name != only) a.dbg = 0; }
         unsigned long long*& stamp_buf = unetpp_dbg_stamp_buf;
         const char* stamp_layer = getenv("UNETPP_WS_STAMPS");      // layer name: print that launch's in-kernel phase times
         const bool stamp_all = stamp_layer && !strcmp(stamp_layer, "all");      // "all": one wall-clock timeline of the forward
