@@ -96,6 +96,18 @@ def conv(x, w, mode):
         wsh = ws.to(torch.float16).to(torch.float64)
         acc = c(xh, wsh) + (c(e5(xl * 256.0), e4(ws / 64.0)) + c(e5(x / 8.0), e4((ws - wsh) * 32.0))) * 0.25
         return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
+    if mode.startswith("y8"):
+        # candidates for a more accurate exact8: activation planes in e4m3 (one more mantissa bit than e5m2, eight binades less
+        # range) with fixed scales 2^LS (residual) and 2^XS (value), saturating.  mode = y8_<LS>_<XS>[_w5]
+        parts = mode.split("_")
+        LS, XS = int(parts[1]), int(parts[2])
+        e4 = lambda t: t.clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64)
+        mx = w.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-30)
+        k = 14 - torch.floor(torch.log2(mx)) - 1
+        ws = w * 2.0 ** k
+        wsh = ws.to(torch.float16).to(torch.float64)
+        acc = c(xh, wsh) + c(e4(xl * 2.0 ** LS), e4(ws / 64.0)) * 2.0 ** (6 - LS) + c(e4(x * 2.0 ** XS), e4((ws - wsh) * 32.0)) * 2.0 ** (-5 - XS)
+        return acc * (2.0 ** -k).reshape(1, -1, 1, 1)
     if mode == "bf8":
         return c(xh, wh) + c(q_e4m3(xl, 2), q_e4m3(w, 2)) + c(q_e4m3(x, 2), q_e4m3(wl, 2))
     raise ValueError(mode)
@@ -108,7 +120,11 @@ def forward(layers, head, x, mode):
             # per-output-channel power-of-two scaling as the engine does (keeps fp16 weights in range)
             t = conv(t, w, mode) + b[None, :, None, None]
             t = torch.relu(t)
-            if mode == "x8":       # stored as fp16 hi + e5m2(2^8 lo): what the next layer (conv, upsample, pool) reads back
+            if mode.startswith("y8"):
+                LS = int(mode.split("_")[1])
+                h = t.to(torch.float16).to(torch.float64)
+                t = h + ((t - h) * 2.0 ** LS).clamp(-448, 448).to(torch.float32).to(torch.float8_e4m3fn).to(torch.float64) / 2.0 ** LS
+            elif mode == "x8":       # stored as fp16 hi + e5m2(2^8 lo): what the next layer (conv, upsample, pool) reads back
                 h = t.to(torch.float16).to(torch.float64)
                 t = h + ((t - h) * 256.0).to(torch.float32).to(torch.float8_e5m2).to(torch.float64) / 256.0
             elif mode != "ref":    # activations are stored as fp16 hi + lo
