@@ -494,7 +494,7 @@ def run_rank(args) -> int:
     if not args.no_fast_leg and world == 1 and not dry:
         del model
         legs = {}
-        for other in [p for p in (("exact", "exact8", "fast") if arch == "nested" else ("exact", "fast")) if p != args.precision]:
+        for other in [p for p in ("exact", "exact8", "fast") if p != args.precision]:
             try:                                            # a leg is informational: its failure must not cost the headline line
                 m2 = make_model(other)
                 dt2, _, _ = timed(m2, args.steps, args.warmup, profile=False)

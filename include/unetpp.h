@@ -47,7 +47,7 @@ enum {
  *   EXACT8 the main term hi * hi of EXACT in fp16, its two small cross terms lo * w and x * w_lo from 8-bit
  *          operands (e5m2 activations, e4m3 weights) in ONE block-scaled K = 64 MFMA per tap pair
  *          (v_mfma_scale_f32_32x32x64_f8f6f4): 2/3 of EXACT's matrix-pipe cycles, logits within 1e-3 of
- *          the fp32 reference (measured <= 5e-4; EXACT: 1e-5, FAST: 5e-3).  NestedUNet only.   */
+ *          the fp32 reference (measured <= 5e-4; EXACT: 1e-5, FAST: 5e-3).  Both architectures.   */
 enum { UNETPP_PREC_EXACT = 0, UNETPP_PREC_FAST = 1, UNETPP_PREC_EXACT8 = 2 };
 
 /* network architecture of an engine */

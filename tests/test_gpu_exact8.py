@@ -246,9 +246,7 @@ def test_exact8_probabilities_and_rules(torch_cuda, syn, oracle):
 
 
 def test_exact8_rejects_what_it_does_not_support(torch_cuda, syn, monkeypatch):
-    from unet_amd.nested_unet import NestedUNet, SimpleUNet
-    with pytest.raises(RuntimeError, match="NestedUNet only"):
-        SimpleUNet(7, 3, precision="exact8", max_batch=1, max_hw=(32, 32)).to("cuda:0")._ensure_engine(1, 32, 32)
+    from unet_amd.nested_unet import NestedUNet
     monkeypatch.setenv("UNETPP_NO_WS", "1")
     with pytest.raises(RuntimeError, match="UNETPP_NO_WS"):
         NestedUNet(3, precision="exact8", max_batch=1, max_hw=(32, 32)).to("cuda:0")._ensure_engine(1, 32, 32)
@@ -378,3 +376,62 @@ def test_exact8_layers_compute_the_documented_arithmetic(torch_cuda, syn, oracle
     v = em.decoder_conv1_layer(act("x3_0", 256, 3), act("x4_0", 512, 4), sd, "conv3_1.conv1", True)
     ref = fp32_layer(torch.cat([T(sk), F.interpolate(T(lo), scale_factor=2, mode="bilinear", align_corners=True)], 1), "conv3_1.conv1")
     check("conv3_1.conv1 (low-resolution GEMM)", rd("x3_1a", 256, 3), v, ref)
+
+
+# ---- SimpleUNet (reference src/models/simple_unet.py:94-128) in exact8: every conv through the wave-specialised
+# kernel (the decoder's cat([up, enc]) as two full-resolution sources), the transposed convs on fp16 terms decoded from the 8-bit
+# residual plane (csrc/convt2x2_mfma.h)
+
+@pytest.mark.parametrize("tag", ["su_c7_32x48", "su_c3_64x40", "su_c7_256x256"])
+def test_exact8_simple_unet_matches_golden(tag, torch_cuda, syn, oracle):
+    torch = torch_cuda
+    from unet_amd.nested_unet import SimpleUNet
+    g = load_golden(tag)
+    B, H, W, C = int(g["B"]), int(g["H"]), int(g["W"]), int(g["num_classes"])
+    frames = syn.make_frames_u8(B, H, W, str(g["kind"]), int(g["fseed"]))
+    sd = syn.make_simple_state_dict(C, 3, int(g["wseed"]))
+    model = SimpleUNet(num_classes=C, num_channels=3, precision="exact8", max_batch=B, max_hw=(H, W)).to("cuda:0")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = torch.from_numpy(syn.frames_to_chw_f32(frames)).cuda()
+    mask, logits = model.segment(x, return_logits=True)
+    m_u8, l_u8 = model.segment(torch.from_numpy(frames).cuda(), return_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(l_u8, logits) and torch.equal(m_u8, mask)          # the uint8 BGR entry computes the same bits
+    lg, mk = logits.cpu().numpy(), mask.cpu().numpy()
+    assert model.status() == 0
+    if "logits" in g.files:
+        gate(tag, lg, mk, g["logits"], g["mask"], oracle)
+        for k in [f for f in g.files if f.startswith("t_")]:              # node by node: exact8-class (2^-13 of the largest value), not fp16-class
+            got = model.debug_activation(k[2:], B, H, W)
+            rel = float(np.abs(got - g[k]).max() / np.abs(g[k]).max())
+            print(f"  {k[2:]}: {rel:.1e} of the largest value")
+            assert rel < 1.5e-4, (k, rel)
+    else:                                                                  # 256 x 256: the fixture holds every fourth logit, the mask and its ties
+        err = float(np.abs(lg[:, :, ::4, ::4] - g["logits_sub4"]).max())
+        ref = oracle.simple_unet_torch_forward(sd, syn.frames_to_chw_f32(frames))
+        assert float(np.abs(ref[:, :, ::4, ::4] - g["logits_sub4"]).max()) < 1e-5      # the oracle is the fixture's reference
+        gate(tag, lg, mk, ref, oracle.masks_from_logits(ref)[0], oracle)
+        assert err < LOGIT_TOL
+
+
+def test_exact8_simple_unet_random_shapes_and_batch_rows(torch_cuda, syn, oracle, monkeypatch):
+    torch = torch_cuda
+    from unet_amd.nested_unet import SimpleUNet
+    monkeypatch.setenv("UNETPP_KSPLIT", "1")             # one launch plan for every batch size: rows must then agree bit for bit
+    rng = np.random.default_rng(52001)
+    for _ in range(6):
+        C = int(rng.integers(1, 9)); B = int(rng.integers(2, 4))
+        H = 8 * int(rng.integers(1, 17)); W = 8 * int(rng.integers(1, 17))
+        sd = syn.make_simple_state_dict(C, 3, int(rng.integers(0, 50)))
+        x = syn.frames_to_chw_f32(syn.make_frames_u8(B, H, W, "smooth", int(rng.integers(0, 1000))))
+        m = SimpleUNet(num_classes=C, num_channels=3, precision="exact8", max_batch=B, max_hw=(H, W)).to("cuda:0")
+        m.load_state_dict(sd, strict=True)
+        ref = oracle.simple_unet_torch_forward(sd, x)
+        xt = torch.from_numpy(x).cuda()
+        mask, logits = m.segment(xt, return_logits=True)
+        one = m(xt[1:2])
+        torch.cuda.synchronize()
+        assert torch.equal(logits[1:2], one), (C, B, H, W)
+        scale = max(1.0, float(np.abs(ref).max()))
+        gate(f"simple C={C} B={B} {H}x{W}", logits.cpu().numpy() / scale, mask.cpu().numpy(), ref / scale, oracle.masks_from_logits(ref)[0], oracle)

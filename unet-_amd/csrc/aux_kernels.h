@@ -166,7 +166,7 @@ __global__ void conv0_pack_kernel(const float* __restrict__ w, const float* __re
 // Input conversion -> [N][1][H][W][P][8] fp16 (one channel block of 8, channels 3..7 zero).
 //   fmt 0: float32 NCHW RGB in [0,1]                    (model(img_tensor), infer_two_stage_burr.py:292-295)
 //   fmt 1: uint8 NHWC BGR: RGB = BGR reversed, /255.0f   (preprocess_image, infer_two_stage_burr.py:122-127)
-template <int P>
+template <int P, bool X8 = false>
 __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N, int H, int W,
                                      half_t* __restrict__ out, unsigned* __restrict__ status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,7 +203,11 @@ __global__ void convert_input_kernel(const void* __restrict__ in, int fmt, int N
   }
   half8* o = (half8*)(out + i * P * 8);
   o[0] = hi;
-  if (P == 2) o[1] = lo;
+  if (X8) {      // EXACT8: the second 16 bytes are {lo8 x 4, x8 x 4} of channels 0..3 (the blue slot and channels 4..7 are zero)
+    unsigned h0, h1, l8, x8;
+    split_pack4_x8(v[0], v[1], v[2], 0.f, h0, h1, l8, x8);
+    *(u32x4*)(o + 1) = (u32x4){l8, x8, 0u, 0u};
+  } else if (P == 2) o[1] = lo;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -260,15 +260,20 @@ __device__ __forceinline__ void split_pack4_x8(float v0, float v1, float v2, flo
   x8 = __builtin_bit_cast(unsigned, u);
 }
 
-template <int P>
+template <int P, bool X8 = false>
 __device__ __forceinline__ void pack_store_octets(const float (&v)[16], half_t* dst, size_t blk_stride, bool ok, int h) {
   unsigned wh[4][2], wl[4][2];
+  if (X8) {      // EXACT8 records: wl[q] = {lo8 x 4, x8 x 4} of the quad's four channels; the same exchange then builds the octet's 16 bytes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pack4_x8(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], wh[q][0], wh[q][1], wl[q][0], wl[q][1]);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
       const float v0 = v[4 * q + 2 * w2], v1 = v[4 * q + 2 * w2 + 1];      // within the fp16 range: the caller clamped
-      if (P == 2) {
+      if (X8) {
+      } else if (P == 2) {
         split_pack2(v0, v1, wh[q][w2], wl[q][w2]);
       } else {
         half2v ph = {(half_t)v0, (half_t)v1};

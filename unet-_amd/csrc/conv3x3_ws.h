@@ -246,7 +246,9 @@ __device__ __forceinline__ void ws_epilogue(const ConvArgs& a, const float16v (&
 // packed conv1 weights (hi/lo split, three MFMAs as everywhere), applies scale/bias/ReLU, writes zeros for halo pixels
 // outside the image (conv2's padding) and stores the hi/lo quads into the halo image.  The two conv2 weight slabs
 // stay in LDS for the whole launch.
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MWP = 4, bool X8 = false>
+// CAT2: the K loop runs over TWO full-resolution tensors (SimpleUNet's cat([up, enc]), simple_unet.py:112,117,122), in0's chunks
+// first; both hold whole 16-channel records (the host checks), so a lane's offsets are those of the first source.
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MWP = 4, bool X8 = false, bool CAT2 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   using C = WsCfg<P, UPF, C0F, NW, MWP, X8>;
   static_assert(!C0F || (!UPF && !HEAD && P == 2 && NW == 1), "fused first block: exact mode, no other fusion in the loader");
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
   constexpr int NT = C::NT, MW = C::MW, TH = C::TH, TW = C::TW, HALO_W = C::HALO_W;
   constexpr int KC = C::KC, KG = C::KG, BN = C::BN, PPP = C::PPP;
   static_assert(!(POOL && HEAD) && !(UPF && (POOL || HEAD)), "one fused extra per kernel");
+  static_assert(!CAT2 || (!UPF && !C0F && !POOL && !HEAD), "two full-resolution sources: the plain kernel only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef UNETPP_WS_DBG
   const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
@@ -699,6 +702,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
         }
       }
       rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in0 + (size_t)n * H * W * P * a.C0), 0, (int)img_bytes0, 0x00020000);
+      if (CAT2)
+        rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 + (size_t)n * H * W * P * a.C1), 0, (int)((unsigned)H * (unsigned)W * (unsigned)(P * a.C1 * 2)), 0x00020000);
       if (UPF) {
         rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 + (size_t)n * Hs * Ws * P * a.C1), 0, (int)img_bytes1, 0x00020000);
         const int ybase = (int)(up_sh * (float)max(y0 - 1, 0)), xbase = (int)(up_sw * (float)max(x0 - 1, 0));
@@ -890,6 +895,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
             const int piece = pw + it * C::NPROD;
             if (C::HALO_PIECES % C::NPROD == 0 || piece < C::HALO_PIECES)
               blds16(rsrc0, voff0[it], c * (int)plane_bytes0, lds_base + buf + piece * 1024);
+          }
+        } else if (CAT2) {                               // chunk of the second full-resolution source
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            const int piece = pw + it * C::NPROD;
+            if (C::HALO_PIECES % C::NPROD == 0 || piece < C::HALO_PIECES)
+              blds16(rsrc1, voff0[it], (c - nch0) * (int)plane_bytes0, lds_base + buf + piece * 1024);
           }
         }
         // A layer of two chunks and one channel tile keeps its weights: chunk c of every tile lands in stage c, so the

@@ -23,7 +23,10 @@ struct ConvTArgs {
   unsigned* status;      // engine's sticky range flags (conv3x3_mfma.h: range_flag)
 };
 
-template <int P>
+// X8 (precision exact8): the input's second plane holds {lo8 x 4, x8 x 4, lo8 x 4, x8 x 4} per channel octet instead of fp16 lo;
+// the residual is decoded back to fp16 (2^-8 e5m2: exact) and the three fp16 terms are issued as in exact mode -- 4 % of the
+// network's flops, not worth a scaled-MFMA path of its own; the output is stored with the 8-bit planes.
+template <int P, bool X8 = false>
 __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -73,7 +76,13 @@ __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
     for (int pt = 0; pt < 4; ++pt) {
       const half_t* x = blk + (size_t)pix[pt] * (P * 16);
       o.xh[pt] = *(const half8*)x;
-      if (P == 2) o.xl[pt] = *(const half8*)(x + 16);
+      if (X8) {
+        const u32x4 b8 = *(const u32x4*)(x + 16);                  // {lo8 c0-3, x8 c0-3, lo8 c4-7, x8 c4-7} of this lane's octet
+        typedef _Float16 half2x __attribute__((ext_vector_type(2)));
+        const half2x q0 = __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(b8[0], X8_LO_MUL, false), q1 = __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(b8[0], X8_LO_MUL, true);
+        const half2x q2 = __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(b8[2], X8_LO_MUL, false), q3 = __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(b8[2], X8_LO_MUL, true);
+        o.xl[pt] = (half8){q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+      } else if (P == 2) o.xl[pt] = *(const half8*)(x + 16);
     }
   };
   auto run_mfma = [&](const Ops& o) {
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void convt2x2_kernel(ConvTArgs a) {
         for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], -F16_MAX, F16_MAX);
       }
       half_t* dst = a.out + ((size_t)n * nbo + (cbase >> 4)) * oblk + ((size_t)(2 * y + dy) * W2 + (2 * x + dx)) * (P * 16);
-      pack_store_octets<P>(v, dst, oblk, ok, h);
+      pack_store_octets<P, X8>(v, dst, oblk, ok, h);
     }
   }
 }

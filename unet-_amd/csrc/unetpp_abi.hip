@@ -142,6 +142,7 @@ struct unetpp_engine {
   int c0f_conv1 = -1;             // index of conv0_0.conv1 in `convs` when the first block is fused, else -1
   int ws_max_cout = 512;          // largest Cout the 8-row wave-specialised tiles are used for (UNETPP_WS_MAX_COUT; measured: every layer gains 1-8 %)
   bool ws64 = true;               // ... and for the Cout = 64 layers (UNETPP_NO_WS64=1: the lock-step kernel there)
+  bool ws_cat = false;            // ... and for convs over two full-resolution sources (exact8; UNETPP_WS_CAT=1: in exact too)
   bool use_ws = true;             // exact-mode convs in the wave-specialised kernel (UNETPP_NO_WS=1: the lock-step one)
   unsigned* d_status = nullptr;   // sticky range flags (UNETPP_STATUS_*), one word inside the arena
   int ksplit_max = 16, ksplit_min_chunks = 4, ksplit_gate = 4;      // split-K of small launches (UNETPP_KSPLIT=max[,min chunks]; 1 = off)
@@ -252,7 +253,7 @@ hipError_t launch_conv_k(const LaunchCtx& cx, const ConvArgs& a, hipStream_t s) 
 }
 
 // wave-specialised kernel (conv3x3_ws.h): 16-row tiles (Cout = 32) or 8-row tiles (Cout % 64 == 0), one persistent workgroup per CU
-template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4, bool X8 = false>
+template <int P, bool POOL, bool HEAD, bool UPF, bool C0F = false, int NW = 1, int MW = 4, bool X8 = false, bool CAT2 = false>
 hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
   using C = WsCfg<P, UPF, C0F, NW, MW, X8>;
   a.tiles_x = (a.W + C::TW - 1) / C::TW; a.tiles_y = (a.H + C::TH - 1) / C::TH; a.nct = a.Cout / C::BN;
@@ -278,7 +279,7 @@ hipError_t launch_ws_k(const LaunchCtx& cx, ConvArgs a, hipStream_t s) {
     a.gdec[3] = t % a.tiles_y;
     a.gdec[4] = t / a.tiles_y;
   }
-  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW, X8>;
+  auto k = conv3x3_ws_kernel<P, POOL, HEAD, UPF, C0F, NW, MW, X8, CAT2>;
   hipError_t st = allow_full_lds((const void*)k, cx.device);
   if (st != hipSuccess) return st;
   hipLaunchKernelGGL(k, grid, dim3(C::NT), lds, s, a);
@@ -291,9 +292,11 @@ hipError_t launch_ws_x(const LaunchCtx& cx, int P, const ConvArgs& a, bool pool,
   if (a.Cout >= 64 && a.Cout % 64 == 0) {      // 8-row tiles, two 32-channel blocks per consumer wave, Cout / 64 channel tiles
     if (head || c0f) return hipErrorInvalidValue;
     if (upf) return launch_ws_k<2, false, false, true, false, 2, 2, X8>(cx, a, s);
-    if (pool) return launch_ws_k<2, true, false, false, false, 2, 2, X8>(cx, a, s);
+    if (pool) return a.in1 ? hipErrorInvalidValue : launch_ws_k<2, true, false, false, false, 2, 2, X8>(cx, a, s);
+    if (a.in1) return launch_ws_k<2, false, false, false, false, 2, 2, X8, true>(cx, a, s);      // two full-resolution sources
     return launch_ws_k<2, false, false, false, false, 2, 2, X8>(cx, a, s);
   }
+  if (a.in1 && !upf) return hipErrorInvalidValue;
   if (a.Cout != 32) return hipErrorInvalidValue;
   if (c0f) return (pool && !head && !upf && a.nchunks == 2) ? launch_ws_k<2, true, false, false, true, 1, 4, X8>(cx, a, s) : hipErrorInvalidValue;
   if (upf) return launch_ws_k<2, false, false, true, false, 1, 4, X8>(cx, a, s);
@@ -608,7 +611,8 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
     return fail(nullptr, UNETPP_E_INVALID, "precision=%d unknown", cfg->precision);
   if (cfg->precision == UNETPP_PREC_EXACT8) {
     // EXACT8 exists in the wave-specialised kernels only: no lock-step / unfused alternatives to switch to
-    if (cfg->arch != UNETPP_ARCH_NESTED) return fail(nullptr, UNETPP_E_UNSUPPORTED, "precision EXACT8 is built for NestedUNet only");
+    // (SimpleUNet: every conv through the wave-specialised kernel -- two full-resolution sources included --, the transposed
+    // convs on fp16 terms decoded from the 8-bit residual plane, convt2x2_mfma.h)
     for (const char* sw : {"UNETPP_NO_WS", "UNETPP_NO_WS64", "UNETPP_WS_MAX_COUT", "UNETPP_NO_C0F", "UNETPP_NO_UPF", "UNETPP_NO_UPF1"})
       if (getenv(sw)) return fail(nullptr, UNETPP_E_UNSUPPORTED, "%s has no meaning with precision EXACT8", sw);
   }
@@ -634,6 +638,9 @@ int unetpp_create(const unetpp_config* cfg, unetpp_engine** out) {
   if (const char* mc = getenv("UNETPP_WS_MAX_COUT")) e->ws_max_cout = atoi(mc);
   e->P = cfg->precision == UNETPP_PREC_FAST ? 1 : 2;
   e->x8 = cfg->precision == UNETPP_PREC_EXACT8;
+  // convs over two full-resolution sources: the wave-specialised kernel in exact8 (the only kernel with that arithmetic);
+  // exact keeps the lock-step kernel (same speed, and its results do not depend on a split-K plan) unless UNETPP_WS_CAT=1
+  { const char* c = getenv("UNETPP_WS_CAT"); e->ws_cat = e->use_ws && (e->x8 || (c && c[0] == '1')); }
   e->mb = (cfg->micro_batch > 0 && cfg->micro_batch < cfg->max_batch) ? cfg->micro_batch : cfg->max_batch;
   e->nstreams = std::max(1, std::min(4, cfg->streams));
   if (e->mb >= cfg->max_batch) e->nstreams = 1;      // a single pass has nothing to overlap with
@@ -754,7 +761,9 @@ size_t unetpp_workspace_bytes(const unetpp_engine* e) { return e ? e->arena_byte
 static unsigned long long* unetpp_dbg_stamp_buf = nullptr;     // measurement build: in-kernel stamps (scripts/ws_stamps.sh)
 #endif
 static bool layer_uses_ws(const unetpp_engine* e, const ConvLayer& L) {
-  return e->use_ws && e->P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf);
+  // two full-resolution sources (SimpleUNet's decoder conv1): whole 16-channel records in both, same kernel (exact8, or UNETPP_WS_CAT=1)
+  const bool cat_ok = L.in2 >= 0 && !L.upf && e->ws_cat && e->tensors[L.in].C % 16 == 0 && e->tensors[L.in2].C % 16 == 0 && !L.do_pool && L.cout % 64 == 0;
+  return e->use_ws && e->P == 2 && (L.cout == 32 || (e->ws64 && L.cout >= 64 && L.cout <= e->ws_max_cout)) && (L.in2 < 0 || L.upf || cat_ok);
 }
 
 // EXACT8: layers whose chunk count is even pair the ninth taps of consecutive chunks (conv3x3_ws.h); the split-K plan then
@@ -928,8 +937,9 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         const char* src = (const char*)dev_input + (in_format == UNETPP_IN_F32_NCHW ? (size_t)b0 * 3 * hw * 4 : (size_t)b0 * hw * 3);
         size_t total = (size_t)nb * hw;
         double bytes = (double)total * (in_format == UNETPP_IN_F32_NCHW ? 12 : 3) + (double)total * P * 16;
-        Lx.run(P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
+        Lx.run(e->x8 ? "convert_input|convert_input_kernel<2, true>" : P == 2 ? "convert_input|convert_input_kernel<2>" : "convert_input|convert_input_kernel<1>", 0, bytes, [&] {
+          if (e->x8) hipLaunchKernelGGL((convert_input_kernel<2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
+          else if (P == 2) hipLaunchKernelGGL(convert_input_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
           else hipLaunchKernelGGL(convert_input_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const void*)src, in_format, nb, h, w, tp(e->t_in8), e->d_status);
           return hipSuccess;
         });
@@ -997,7 +1007,7 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         char lbl[160];
         // labels end in the kernel's full template argument list, as rocprofv3 prints it (bench.py matches on it)
         auto tf = [](bool v) { return v ? "true" : "false"; };
-        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2, tf(e->x8));
+        if (ws) snprintf(lbl, sizeof lbl, "%s%s%s%s|conv3x3_ws_kernel<%d, %s, %s, %s, %s, %d, %d, %s, %s>", L.c0f ? "input+conv0_0.conv1+" : "", L.name.c_str(), L.upf ? "+up" : "", head ? "+final+argmax" : "", P, tf(L.do_pool), tf(head), tf(L.upf), tf(L.c0f), L.cout == 32 ? 1 : 2, L.cout == 32 ? 4 : 2, tf(e->x8), tf(L.in2 >= 0 && !L.upf));
         else snprintf(lbl, sizeof lbl, "%s%s%s|conv3x3_bias_relu_kernel<%d, %d, %d, %d, %d, %s, %s, %s, %s>", L.name.c_str(), L.upf ? "+up" : (L.zt >= 0 ? ".skip+z" : ""), head ? "+final+argmax" : "", P, L.KC, L.NW, mw, L.WAVES, tf(L.do_pool), tf(head), tf(L.upf), tf(L.zt >= 0));
         Lx.run(lbl, flops, bytes, [&] {
           return ws ? launch_ws(LaunchCtx{e->cfg.device, e->num_cus, e->ksplit_max, e->ksplit_min_chunks, e->ksplit_gate}, P, e->x8, a, L.do_pool, head, L.upf, L.c0f, s)
@@ -1108,9 +1118,11 @@ int unetpp_forward_ex(unetpp_engine* e, const void* dev_input, int in_format, in
         double bytes = px * P * 2.0 * (T.cin + 4.0 * T.cout) + 4.0 * T.cin * T.cout * 2.0 * P;
         dim3 grid((unsigned)(((H * W + 511) / 512) * (4 * T.cout / 64) * nb));
         char lbl[96];
-        snprintf(lbl, sizeof lbl, "%s|convt2x2_kernel<%d>", T.name.c_str(), P);
+        if (e->x8) snprintf(lbl, sizeof lbl, "%s|convt2x2_kernel<2, true>", T.name.c_str());
+        else snprintf(lbl, sizeof lbl, "%s|convt2x2_kernel<%d>", T.name.c_str(), P);
         Lx.run(lbl, flops, bytes, [&] {
-          if (P == 2) hipLaunchKernelGGL(convt2x2_kernel<2>, grid, dim3(256), 0, s, a);
+          if (e->x8) hipLaunchKernelGGL((convt2x2_kernel<2, true>), grid, dim3(256), 0, s, a);
+          else if (P == 2) hipLaunchKernelGGL(convt2x2_kernel<2>, grid, dim3(256), 0, s, a);
           else hipLaunchKernelGGL(convt2x2_kernel<1>, grid, dim3(256), 0, s, a);
           return hipSuccess;
         });
