@@ -202,12 +202,22 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 // The same for a buffer-addressed source: per-lane byte offset `voff` into the buffer `rsrc` plus the
 // wave-uniform `soff`; lanes whose offset lies outside the buffer write ZEROS to their 16 bytes of LDS
 // (checked on gfx950) -- which is how the convolution's zero padding gets into the halo image.
+template <bool NT = false>
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
-               : "memory");
+  // NT: the `nt` cache policy for bytes this launch reads (almost) once -- a conv's halo rows: one frame per call takes 4-5 % less (the first chunk
+  // lands sooner), batch 16 is unchanged (profiles/r03_halo_nt_ab.txt).  Not for tiles that neighbours re-read
+  // out of the L2 (the low-resolution GEMM's operand, the up-sum's Y): those got slower.
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+                 : "memory");
 }
 
 // Epilogue helper shared by the conv and transposed-conv kernels.  `v` = the 16 channel values of one pixel
@@ -341,6 +351,8 @@ __device__ __forceinline__ void pack_store_rows8(const float (&v)[16], half_t* d
     }
 #endif
     if (ok) {
+      // (streaming `nt` stores here: one frame per call 2 % sooner in the layer table, nothing in bench.py's median, batch 16 0.6-1 %
+      // later -- also as a per-launch switch for small launches; not kept.  profiles/r03_halo_nt_ab.txt)
       *(u32x4*)(dst + pi * blk_stride + 8 * h) = (u32x4){wh[0], wh[1], wh[2], wh[3]};
       if (P == 2) *(u32x4*)(dst + pi * blk_stride + 16 + 8 * h) = (u32x4){wl[0], wl[1], wl[2], wl[3]};
     }
@@ -494,7 +506,7 @@ void conv3x3_bias_relu_kernel(ConvArgs a) {
     if (C::HALO_PIECES % WAVES != 0 && piece >= C::HALO_PIECES) return;
     const unsigned dst = lds_base + halo_off + piece * 1024;
     // scalar offset = first channel block of the chunk
-    if (c < nch0) blds16(rsrc0, voff0[it], c * (KC / 16) * (int)plane_bytes0, dst);
+    if (c < nch0) blds16(rsrc0, voff0[it], c * (KC / 16) * (int)plane_bytes0, dst);        // (nt measured 1.5-2 % slower in this kernel)
     else if (!UPF) blds16(rsrc1, voff1[it], (c - nch0) * (KC / 16) * (int)plane_bytes1, dst);
   };
   // UPF: staging piece `it` of this wave for up-chunk c -> staging buffer (c & 1)

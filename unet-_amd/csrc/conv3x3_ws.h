@@ -894,14 +894,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvArgs a) {
           for (int it = 0; it < ITERS; ++it) {
             const int piece = pw + it * C::NPROD;
             if (C::HALO_PIECES % C::NPROD == 0 || piece < C::HALO_PIECES)
-              blds16(rsrc0, voff0[it], c * (int)plane_bytes0, lds_base + buf + piece * 1024);
+              blds16<true>(rsrc0, voff0[it], c * (int)plane_bytes0, lds_base + buf + piece * 1024);
           }
         } else if (CAT2) {                               // chunk of the second full-resolution source
 #pragma unroll
           for (int it = 0; it < ITERS; ++it) {
             const int piece = pw + it * C::NPROD;
             if (C::HALO_PIECES % C::NPROD == 0 || piece < C::HALO_PIECES)
-              blds16(rsrc1, voff0[it], (c - nch0) * (int)plane_bytes0, lds_base + buf + piece * 1024);
+              blds16<true>(rsrc1, voff0[it], (c - nch0) * (int)plane_bytes0, lds_base + buf + piece * 1024);
           }
         }
         // A layer of two chunks and one channel tile keeps its weights: chunk c of every tile lands in stage c, so the
